@@ -1,0 +1,118 @@
+"""Pin the CPU oracle against the fixtures produced by the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from parity_utils import first_ambiguous_iteration
+
+TOL = 1e-4  # the contract: fp32 outputs within 1e-4 of the reference CPU path
+
+
+def _weights(synth, g):
+    gsd = synth.generator_state(int(g["z_dim"]), 1, 64, seed=int(g["gen_seed"]))
+    csd = synth.resnet_state("ResNet50", 1, int(g["n_class"]), seed=int(g["cnn_seed"]))
+    if "gen_ck" in g.files:
+        assert synth.checksum(gsd) == str(g["gen_ck"]) and synth.checksum(csd) == str(g["cnn_ck"])
+    return synth.to_torch(gsd), synth.to_torch(csd)
+
+
+def _class_index(g):
+    return sorted(g["iid"].tolist()).index(int(g["label"])) if "iid" in g.files else 1
+
+
+def test_layers(oracle, synth):
+    g = load_golden("layers")
+    for tag, zd in (("z10", 10), ("z100", 100)):
+        gsd = synth.to_torch(synth.generator_state(zd, 1, 64, seed=int(g["gen_seed"])))
+        csd = synth.to_torch(synth.resnet_state("ResNet50", 1, 8, seed=int(g["cnn_seed"])))
+        z = torch.from_numpy(g[tag + "_z"]).float().reshape(4, zd, 1, 1)
+        with torch.no_grad():
+            img, (a1, a2) = oracle.generator_forward(gsd, z, stages=True)
+            img01 = oracle.rescale_per_image(img)
+            logits, st = oracle.resnet_forward(csd, img01, stages=True)
+        for name, got in [("a1", a1), ("a2", a2), ("img", img), ("img01", img01), ("stem", st[0]), ("s1", st[1]),
+                          ("s2", st[2]), ("s3", st[3]), ("s4", st[4]), ("logits", logits)]:
+            ref = g[f"{tag}_{name}"]
+            np.testing.assert_allclose(got.numpy(), ref, rtol=1e-4, atol=1e-4, err_msg=f"{tag} {name}")
+        ci = sorted(g[tag + "_iid"].tolist()).index(int(g[tag + "_label"]))
+        f = oracle.fitness_from_logits(logits, ci, "optimize_out_training", 0.0, 0.1).numpy()
+        np.testing.assert_allclose(f, g[tag + "_fitness"], atol=TOL)
+
+
+@pytest.mark.parametrize("name", ["swarm_n8_t5_z10", "swarm_n64_t50_z10", "swarm_n16_t30_z100_sched_es",
+                                  "swarm_n12_t40_z10_es"])
+def test_swarm_trajectory(oracle, synth, name):
+    """Same seeds in -> the oracle reproduces the reference's whole trajectory."""
+    g = load_golden(name)
+    gsd, csd = _weights(synth, g)
+    fit = oracle.Fitness(gsd, csd, _class_index(g), str(g["mode"]))
+    n, d = int(g["n"]), int(g["d"])
+    np.random.seed(int(g["np_seed"]))
+    pos, vel = oracle.init_swarm(n, d)
+    np.testing.assert_array_equal(pos, g["pos"][0])
+    np.testing.assert_array_equal(vel, g["vel"][0])
+    w = g["w"]
+    batch = 1 if n <= 16 else n  # batch-1 like the reference on the small cases
+    out = oracle.run_swarm(fit, pos, vel, int(g["t"]), w[0], w[1], w[2], tolerance=float(g["tolerance"]),
+                           schedule_inertia=bool(g["schedule_inertia"]), early_stopping=bool(g["early_stopping"]),
+                           batch=batch)
+    iters = g["fitness"].shape[0]
+    if batch != 1:
+        # batched CPU convolutions round differently from batch-1 ones (~5e-6 on the fitness):
+        # the trajectory is comparable while every decision has a larger margin than that
+        safe = first_ambiguous_iteration(g["fitness"], 5e-5)
+        assert safe >= 6
+        np.testing.assert_allclose(np.stack(out["fitness"])[:safe], g["fitness"][:safe], atol=TOL)
+        np.testing.assert_allclose(np.stack(out["pos"])[:safe + 1], g["pos"][:safe + 1], rtol=1e-9, atol=1e-9)
+        # and per step everywhere: the reference's positions in, the reference's fitness out
+        for t in range(0, iters, 7):
+            np.testing.assert_allclose(fit(g["pos"][t]), g["fitness"][t], atol=TOL)
+        return
+    assert out["i"] == int(g["i_ret"])
+    assert len(out["fitness"]) == iters
+    np.testing.assert_allclose(np.stack(out["fitness"]), g["fitness"], atol=TOL)
+    np.testing.assert_allclose(np.stack(out["pos"]), g["pos"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(np.stack(out["vel"]), g["vel"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(out["mean_mse"], g["mean_mse"], rtol=1e-12)
+    np.testing.assert_allclose(np.array(out["g_best_val"], np.float32), g["g_best_val"], atol=TOL)
+    np.testing.assert_allclose(np.array(out["g_best_val_dummy"], np.float32), g["g_best_val_dummy"], atol=TOL)
+    np.testing.assert_allclose(out["g_best_pos"], g["g_best_pos"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(out["pbest_pos"], g["pbest_pos"], rtol=1e-9, atol=1e-9)
+    assert abs(out["w_inertia"] - float(g["w_inertia_final"])) < 1e-15
+
+
+def test_rand_replay_matches_draw_order(oracle):
+    """r1/r2 stored in the fixtures are the reference's own draws: feeding them back
+    explicitly gives the same trajectory as drawing from the seeded global stream."""
+    g = load_golden("swarm_n8_t5_z10")
+    calls = iter(g["fitness"])
+    out = oracle.run_swarm(lambda p, s: next(calls), g["pos"][0], g["vel"][0], int(g["t"]), *g["w"],
+                           early_stopping=False, rand=g["rand"], batch=8)
+    np.testing.assert_array_equal(np.stack(out["pos"]), g["pos"])
+
+
+def test_toy_known_answer(oracle):
+    """Reference hands_on/pso.py on the sphere function: converges to ~0 and stops early."""
+    g = load_golden("toy_sphere")
+    np.random.seed(42)
+    r = np.stack([np.stack([np.random.uniform(-5, 5, 3), (np.random.randn(3) - 0.5) / 10]) for _ in range(20)])
+    np.testing.assert_array_equal(r[:, 0], g["pos0"])
+    sphere = lambda p, s: np.sum(p * p, axis=1)  # float64 objective, like the toy
+    out = oracle.run_swarm(sphere, r[:, 0], r[:, 1], 100, *g["w"], tolerance=float(g["tolerance"]),
+                           early_stopping=True, batch=20, diagnostics=False)
+    np.testing.assert_allclose(np.array(out["g_best_val"], np.float64), g["g_best_val"], rtol=1e-6)
+    np.testing.assert_allclose(out["g_best_pos"], g["g_best_pos"], rtol=1e-5, atol=1e-7)
+    assert out["g_best_val"][-1] < 1e-3
+
+
+def test_assessor_shapes(oracle, synth):
+    g = load_golden("assessor_shapes")
+    x = torch.from_numpy(g["x64"])
+    for model in ("ResNet50", "ResNet101"):
+        csd = synth.to_torch(synth.resnet_state(model, 1, 8, seed=12))
+        with torch.no_grad():
+            np.testing.assert_allclose(oracle.resnet_forward(csd, x).numpy(), g[f"{model}_logits64"], rtol=1e-4, atol=1e-4)
+            np.testing.assert_allclose(oracle.resnet_forward(csd, x[:, :, :28, :28].contiguous()).numpy(),
+                                       g[f"{model}_logits28"], rtol=1e-4, atol=1e-4)
