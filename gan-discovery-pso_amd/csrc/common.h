@@ -1,0 +1,102 @@
+// Internal declarations shared by the translation units of libgdpso.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/gdpso.h"
+
+namespace gdpso {
+
+void set_error(const std::string &msg);
+int fail(int code, const std::string &msg);
+
+#define GDPSO_HIP(expr)                                                                         \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess)                                                                   \
+            return ::gdpso::fail(GDPSO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+#define GDPSO_REQUIRE(cond, msg)                                      \
+    do {                                                              \
+        if (!(cond)) return ::gdpso::fail(GDPSO_ERR_ARG, (msg));      \
+    } while (0)
+
+constexpr int MAX_TAPS = 64;   // 7x7 = 49 is the largest window on the path
+constexpr int MAX_PHASES = 4;  // sub-pixel phases of a stride-2 transposed convolution
+
+// Activation applied in a convolution's epilogue.
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY02 = 2 };
+
+// One convolution (or one transposed convolution split into sub-pixel phases) expressed as
+// an implicit GEMM over NHWC activations:
+//   out[pix(m), co] = act( scale[co] * sum_{t,ci} in[n, my*in_stride + dy[t], mx*in_stride + dx[t], ci]
+//                                               * wt[co][t*cin + ci]  + shift[co] (+ res[pix(m), co]) )
+// with m = (n, my, mx) over an hm x wm grid and pix(m) = (n, my*out_mul + off_y, mx*out_mul + off_x).
+// Taps that fall outside the input read zeros.  Only taps that can ever be in range are kept.
+struct ConvPhase {
+    int ntaps;
+    int off_y, off_x;      // output offset of this phase
+    long wt_offset;        // element offset of this phase's [cout][ntaps*cin] matrix
+    int8_t dy[MAX_TAPS];
+    int8_t dx[MAX_TAPS];
+};
+
+struct ConvLayer {
+    int cin, cout;
+    int hin, win;
+    int hm, wm;
+    int hout, wout;
+    int in_stride, out_mul;
+    int nphase;
+    int act;
+    ConvPhase phase[MAX_PHASES];
+    const float *wt;     // device
+    const float *scale;  // device [cout] (never null)
+    const float *shift;  // device [cout]
+    const int *table;    // device [nphase][4 + MAX_TAPS]: {ntaps, off_y, off_x, wt_offset, (dy | dx<<16)...}
+    // launch plan (chosen once per batch size by plan_conv)
+    int tile;            // 128 or 64
+    int splits;          // split-K factor
+    double flops_nominal;  // per image: 2 * out_pixels * cout * cin * kh * kw (padding taps included)
+};
+
+// conv_gemm.hip
+int plan_conv(ConvLayer &L, int n_images, int num_cus);
+size_t conv_splitk_bytes(const ConvLayer &L, int n_images);
+int launch_conv(const ConvLayer &L, hipStream_t stream, int n_images, const float *in, const float *res,
+                float *out, float *splitk_ws);
+
+// host-side helpers (pack.cpp)
+struct DeviceArena {
+    std::vector<void *> blocks;
+    ~DeviceArena();
+    int upload(const void *host, size_t bytes, const void **dev);
+    int upload(const std::vector<float> &host, const float **dev) {
+        return upload(host.data(), host.size() * sizeof(float), (const void **)dev);
+    }
+};
+
+// Uploads a layer's packed weights, scale/shift and tap table; fills the device pointers.
+int upload_conv(DeviceArena &arena, ConvLayer &L, const std::vector<float> &packed,
+                const std::vector<float> &scale, const std::vector<float> &shift);
+
+// Folds an eval-mode BatchNorm (and an optional preceding bias) into y = acc*scale + shift.
+void fold_bn(int c, const float *bias, const float *gamma, const float *beta, const float *mean,
+             const float *var, std::vector<float> &scale, std::vector<float> &shift);
+
+// Builds an ordinary convolution layer from a PyTorch [cout][cin][kh][kw] weight.
+// Returns the packed weights through `packed` (the caller uploads them).  cin is padded
+// with zero weights to `cin_pad` and cout to `cout_pad` (both multiples the kernel needs).
+void make_conv(ConvLayer &L, const float *w, int cout, int cin, int kh, int kw, int stride, int pad,
+               int hin, int win, int act, std::vector<float> &packed, int cin_pad = 0, int cout_pad = 0);
+
+// Builds the 4-phase form of ConvTranspose2d(k4, s2, p1) from a PyTorch [cin][cout][4][4] weight.
+void make_convt_k4s2p1(ConvLayer &L, const float *w, int cin, int cout, int hin, int win, int act,
+                       std::vector<float> &packed);
+
+inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace gdpso

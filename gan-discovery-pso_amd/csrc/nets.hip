@@ -1,0 +1,678 @@
+// Generator, assessor and encoder forward passes: the non-GEMM kernels (Cin = 1 or
+// Cout = 1 layers, pooling, per-image reductions, classifier + fitness) and the plans
+// that chain them with the implicit-GEMM convolution kernel.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "common.h"
+
+namespace gdpso {
+
+// ---------------------------------------------------------------------------------
+// Latents: float64 (or float32) positions -> float32 rows zero-padded to the GEMM's K.
+// The float64 -> float32 cast is the one at reference src/pso/util_discovery.py:41-43.
+__global__ __launch_bounds__(256) void latent_prep_kernel(const void *__restrict__ z, int z_is_f64, int n, int zd,
+                                                          int kpad, float *__restrict__ out) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)n * kpad) return;
+    const int row = (int)(e / kpad), col = (int)(e - (long)row * kpad);
+    float v = 0.f;
+    if (col < zd) v = z_is_f64 ? (float)((const double *)z)[(long)row * zd + col] : ((const float *)z)[(long)row * zd + col];
+    out[e] = v;
+}
+
+// ---------------------------------------------------------------------------------
+// Last generator layer, fused: ConvTranspose2d(F -> 1, k4, s2, p1) + bias + tanh
+// (reference src/utils/util_dcgan.py:137-138), per-image min/max rescale to [0,1]
+// (src/utils/util_data.py:129-135 on a batch of one) and, optionally, the pixel MSE
+// against a target image (src/pso/util_discovery.py:97).
+// One workgroup per image.  16 lanes share one output pixel (4 channels each, float4
+// loads of the NHWC input), so a wave produces 4 pixels per pass.
+__global__ __launch_bounds__(256) void gen_last_kernel(const float *__restrict__ a2, const float *__restrict__ w5,
+                                                       float bias, int hin, int cin, float *__restrict__ img,
+                                                       float *__restrict__ img01, const float *__restrict__ target,
+                                                       float *__restrict__ mse) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int side = 2 * hin, npix = side * side;
+    float *s_w = smem;               // [16][cin]
+    float *s_img = smem + 16 * cin;  // [npix]
+    float *s_red = s_img + npix;     // [12]: min, max, squared error of the 4 waves
+    const int tid = threadIdx.x, n = blockIdx.x;
+    for (int i = tid; i < 16 * cin; i += 256) s_w[i] = w5[i];
+    __syncthreads();
+    const int grp = tid >> 4, sub = tid & 15;
+    const float *src = a2 + (size_t)n * hin * hin * cin;
+    for (int p0 = 0; p0 < npix; p0 += 16) {
+        const int p = p0 + grp;
+        float acc = 0.f;
+        if (p < npix) {
+            const int oy = p / side, ox = p - oy * side;
+            const int py = oy & 1, px = ox & 1, my = oy >> 1, mx = ox >> 1;
+#pragma unroll
+            for (int ty = 0; ty < 2; ++ty) {
+                const int iy = my + (ty == 0 ? 0 : (py ? 1 : -1));
+                const int ky = py ? (ty == 0 ? 2 : 0) : (ty == 0 ? 1 : 3);
+                if ((unsigned)iy >= (unsigned)hin) continue;
+#pragma unroll
+                for (int tx = 0; tx < 2; ++tx) {
+                    const int ix = mx + (tx == 0 ? 0 : (px ? 1 : -1));
+                    const int kx = px ? (tx == 0 ? 2 : 0) : (tx == 0 ? 1 : 3);
+                    if ((unsigned)ix >= (unsigned)hin) continue;
+                    const float *row = src + (size_t)(iy * hin + ix) * cin;
+                    const float *wr = s_w + (ky * 4 + kx) * cin;
+                    for (int c = sub * 4; c < cin; c += 64) {
+                        const float4 v = *(const float4 *)(row + c);
+                        const float4 w = *(const float4 *)(wr + c);
+                        acc = fmaf(v.x, w.x, acc);
+                        acc = fmaf(v.y, w.y, acc);
+                        acc = fmaf(v.z, w.z, acc);
+                        acc = fmaf(v.w, w.w, acc);
+                    }
+                }
+            }
+        }
+        acc += __shfl_xor(acc, 8, 16);
+        acc += __shfl_xor(acc, 4, 16);
+        acc += __shfl_xor(acc, 2, 16);
+        acc += __shfl_xor(acc, 1, 16);
+        if (sub == 0 && p < npix) s_img[p] = tanhf(acc + bias);
+    }
+    __syncthreads();
+    // per-image min / max: wavefront shuffle reduction, then across the 4 waves
+    float mn = INFINITY, mx = -INFINITY, se = 0.f;
+    float *dst = img ? img + (size_t)n * npix : nullptr;
+    const float *tg = target ? target + (size_t)n * npix : nullptr;
+    for (int i = tid; i < npix; i += 256) {
+        const float v = s_img[i];
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+        if (dst) dst[i] = v;
+        if (tg) {
+            const float dlt = tg[i] - v;
+            se = fmaf(dlt, dlt, se);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, o));
+        mx = fmaxf(mx, __shfl_xor(mx, o));
+        se += __shfl_xor(se, o);
+    }
+    if ((tid & 63) == 0) {
+        s_red[tid >> 6] = mn;
+        s_red[4 + (tid >> 6)] = mx;
+        s_red[8 + (tid >> 6)] = se;
+    }
+    __syncthreads();
+    mn = fminf(fminf(s_red[0], s_red[1]), fminf(s_red[2], s_red[3]));
+    mx = fmaxf(fmaxf(s_red[4], s_red[5]), fmaxf(s_red[6], s_red[7]));
+    const float range = mx - mn;
+    float *d01 = img01 + (size_t)n * npix;
+    for (int i = tid; i < npix; i += 256) d01[i] = (s_img[i] - mn) / range;
+    if (mse && tid == 0) mse[n] = ((s_red[8] + s_red[9]) + (s_red[10] + s_red[11])) / (float)npix;
+}
+
+// ---------------------------------------------------------------------------------
+// Assessor stem, fused: Conv2d(1 -> 64, k7, s2, p3, no bias) + BatchNorm + ReLU +
+// MaxPool2d(3, s2, p1) (reference src/pso/util_cnn.py:85-88, 103-106).  NHWC output.
+// Grid (image, band of pooled rows).  Lane = output channel (its 49 weights live in
+// registers); the four waves take conv pixels round-robin, reading the zero-padded image
+// from LDS as wave-wide broadcasts.  Conv rows of the band stay in LDS for the pooling.
+__global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ img01, const float *__restrict__ w,
+                                                   const float *__restrict__ scale, const float *__restrict__ shift,
+                                                   int side, int ho, int hp, int band, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int pside = side + 6;
+    float *s_img = smem;                   // [(side+6)^2], zero border of 3
+    float *s_conv = smem + pside * pside;  // [(2*band+1)][ho][64]
+    const int tid = threadIdx.x, c = tid & 63, q = tid >> 6;
+    const int n = blockIdx.x, pr0 = blockIdx.y * band;
+    const int pr1 = min(hp, pr0 + band);
+    const int cr0 = 2 * pr0 - 1, cr1 = 2 * (pr1 - 1) + 1;  // conv rows needed (may stick out)
+    const float *src = img01 + (size_t)n * side * side;
+    for (int i = tid; i < pside * pside; i += 256) {
+        const int y = i / pside - 3, x = i % pside - 3;
+        s_img[i] = ((unsigned)y < (unsigned)side && (unsigned)x < (unsigned)side) ? src[y * side + x] : 0.f;
+    }
+    float wreg[49];
+#pragma unroll
+    for (int t = 0; t < 49; ++t) wreg[t] = w[t * 64 + c];
+    const float sc = scale[c], sh = shift[c];
+    __syncthreads();
+    const int rows = cr1 - cr0 + 1;
+    for (int p = q; p < rows * ho; p += 4) {
+        const int r = p / ho, cx = p - r * ho, cy = cr0 + r;
+        float v = 0.f;
+        if ((unsigned)cy < (unsigned)ho) {
+            const float *base = s_img + (2 * cy) * pside + 2 * cx;  // padded coords: +3 - 3
+            float acc = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx) acc = fmaf(base[ky * pside + kx], wreg[ky * 7 + kx], acc);
+            v = fmaxf(acc * sc + sh, 0.f);
+        }
+        s_conv[p * 64 + c] = v;
+    }
+    __syncthreads();
+    for (int p = q; p < (pr1 - pr0) * hp; p += 4) {
+        const int pr = pr0 + p / hp, pc = p % hp;
+        float m = -INFINITY;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int cy = 2 * pr + dy;
+            if ((unsigned)cy >= (unsigned)ho) continue;
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int cx = 2 * pc + dx;
+                if ((unsigned)cx >= (unsigned)ho) continue;
+                m = fmaxf(m, s_conv[((cy - cr0) * ho + cx) * 64 + c]);
+            }
+        }
+        out[(((size_t)n * hp + pr) * hp + pc) * 64 + c] = m;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Assessor head, fused: AdaptiveMaxPool2d(1) over the last feature map, Linear(C -> n_class)
+// (reference src/pso/util_cnn.py:113-115), softmax + class pick + clamp + mode + eps
+// (src/pso/util_discovery.py:69-80) and the inverter variant's weighted sum (:86-101).
+// One workgroup per image; per-class dot products reduced by wavefront shuffles.
+constexpr int MAX_CLASSES = 64;
+
+__global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ feat, int hw, int c, const float *__restrict__ fc_w,
+                                                   const float *__restrict__ fc_b, int n_class, float *__restrict__ logits,
+                                                   float *__restrict__ fitness, int class_index, int mode, float threshold,
+                                                   float eps, const float *__restrict__ mse, float w_ass, float w_rec) {
+    __shared__ float s_part[4][MAX_CLASSES];
+    __shared__ float s_logit[MAX_CLASSES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = blockIdx.x;
+    const float *src = feat + (size_t)n * hw * c;
+    // spatial max of this thread's channels: 4 consecutive channels per 1024-channel chunk (c <= 2048)
+    float4 pooled[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int ch = tid * 4 + u * 1024;
+        pooled[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ch < c) {
+            float4 v = *(const float4 *)(src + ch);
+            for (int p = 1; p < hw; ++p) {
+                const float4 t = *(const float4 *)(src + (size_t)p * c + ch);
+                v.x = fmaxf(v.x, t.x); v.y = fmaxf(v.y, t.y); v.z = fmaxf(v.z, t.z); v.w = fmaxf(v.w, t.w);
+            }
+            pooled[u] = v;
+        }
+    }
+    for (int k = 0; k < n_class; ++k) {
+        float acc = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int ch = tid * 4 + u * 1024;
+            if (ch < c) {
+                const float4 w = *(const float4 *)(fc_w + (size_t)k * c + ch);
+                acc = fmaf(pooled[u].x, w.x, acc);
+                acc = fmaf(pooled[u].y, w.y, acc);
+                acc = fmaf(pooled[u].z, w.z, acc);
+                acc = fmaf(pooled[u].w, w.w, acc);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) s_part[wave][k] = acc;
+    }
+    __syncthreads();
+    if (tid < n_class) {
+        const float l = ((s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid])) + fc_b[tid];
+        s_logit[tid] = l;
+        if (logits) logits[(size_t)n * n_class + tid] = l;
+    }
+    __syncthreads();
+    if (tid == 0 && fitness) {
+        float m = -INFINITY;
+        for (int k = 0; k < n_class; ++k) m = fmaxf(m, s_logit[k]);
+        float sum = 0.f;
+        for (int k = 0; k < n_class; ++k) sum += expf(s_logit[k] - m);
+        const int sel = n_class > 2 ? class_index : 1;
+        const float p = expf(s_logit[sel] - m) / sum;
+        const float pc = fminf(p + threshold, 1.0f);
+        float f = (mode == GDPSO_MODE_IN_TRAINING ? pc : (1.0f - pc)) + eps;
+        if (mse) f = (w_ass * f + w_rec * mse[n]) + eps;
+        fitness[n] = f;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Encoder first layer: Conv2d(1 -> F, k4, s2, p1) + bias + LeakyReLU(0.2)
+// (reference src/inverter/utils_ae/util_inverter.py:170-171).  Same mapping as the stem.
+__global__ __launch_bounds__(256) void enc_first_kernel(const float *__restrict__ img, const float *__restrict__ w,
+                                                        const float *__restrict__ bias, int side, int ho, int cout,
+                                                        float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int pside = side + 2;
+    const int tid = threadIdx.x, n = blockIdx.x;
+    const float *src = img + (size_t)n * side * side;
+    for (int i = tid; i < pside * pside; i += 256) {
+        const int y = i / pside - 1, x = i % pside - 1;
+        smem[i] = ((unsigned)y < (unsigned)side && (unsigned)x < (unsigned)side) ? src[y * side + x] : 0.f;
+    }
+    __syncthreads();
+    for (int c = tid & 63; c < cout; c += 64) {
+        float wreg[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) wreg[t] = w[t * cout + c];
+        const float b = bias[c];
+        for (int p = tid >> 6; p < ho * ho; p += 4) {
+            const int cy = p / ho, cx = p - cy * ho;
+            const float *base = smem + (2 * cy) * pside + 2 * cx;
+            float acc = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 4; ++kx) acc = fmaf(base[ky * pside + kx], wreg[ky * 4 + kx], acc);
+            acc += b;
+            out[((size_t)n * ho * ho + p) * cout + c] = acc > 0.f ? acc : 0.2f * acc;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void slice_cols_kernel(const float *__restrict__ in, int ld, int n, int cols,
+                                                         float *__restrict__ out) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)n * cols) return;
+    const int r = (int)(e / cols), c = (int)(e - (long)r * cols);
+    out[e] = in[(size_t)r * ld + c];
+}
+
+static int device_cus() {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus > 0 ? cus : 256;
+}
+
+static size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+}  // namespace gdpso
+
+using namespace gdpso;
+
+// ============================================================================ generator
+struct gdpso_generator {
+    int z_dim, kpad, features, k1, side;
+    ConvLayer l1, l2;
+    const float *w5;
+    float b5;
+    int num_cus;
+    DeviceArena arena;
+};
+
+namespace {
+struct GenLayout {
+    size_t zpad, a1, a2, splitk, total;
+};
+GenLayout gen_layout(const gdpso_generator *g, int n, ConvLayer &l1, ConvLayer &l2) {
+    l1 = g->l1;
+    l2 = g->l2;
+    plan_conv(l1, n, g->num_cus);
+    plan_conv(l2, n, g->num_cus);
+    GenLayout L;
+    size_t off = 0;
+    L.zpad = off; off += align_up((size_t)n * g->kpad * 4);
+    L.a1 = off;   off += align_up((size_t)n * g->k1 * g->k1 * 2 * g->features * 4);
+    L.a2 = off;   off += align_up((size_t)n * 4 * g->k1 * g->k1 * g->features * 4);
+    L.splitk = off; off += align_up(std::max(conv_splitk_bytes(l1, n), conv_splitk_bytes(l2, n)));
+    L.total = off;
+    return L;
+}
+}  // namespace
+
+extern "C" int gdpso_generator_create(gdpso_generator **out, int z_dim, int features_g, int first_kernel,
+                                      const float *const *t, int n_tensors) {
+    GDPSO_REQUIRE(out && t, "generator_create: null argument");
+    GDPSO_REQUIRE(n_tensors == 14, "generator_create: expected 14 tensors");
+    GDPSO_REQUIRE(z_dim > 0 && features_g >= 32 && features_g % 32 == 0, "generator_create: features_g must be a multiple of 32");
+    GDPSO_REQUIRE(first_kernel >= 1 && first_kernel * first_kernel * 2 * features_g % 64 == 0, "generator_create: bad first_kernel");
+    auto g = new gdpso_generator();
+    g->z_dim = z_dim;
+    g->kpad = (z_dim + 31) / 32 * 32;
+    g->features = features_g;
+    g->k1 = first_kernel;
+    g->side = 4 * first_kernel;
+    g->num_cus = device_cus();
+    const int c1 = 2 * features_g, c2 = features_g, k = first_kernel;
+    int rc;
+    {
+        // ConvTranspose2d(Z -> 2F, k, s1, p0) on a 1x1 input is a GEMM [n,Z] x [Z, k*k*2F]; its
+        // columns are ordered (ky, kx, co) so the result is already the NHWC map [n,k,k,2F].
+        std::vector<float> w((size_t)z_dim * k * k * c1), sc, sh, sc1, sh1;
+        // view as Conv2d weight [cout' = k*k*c1][cin = Z][1][1]
+        for (int ci = 0; ci < z_dim; ++ci)
+            for (int co = 0; co < c1; ++co)
+                for (int p = 0; p < k * k; ++p) w[((size_t)p * c1 + co) * z_dim + ci] = t[0][((size_t)ci * c1 + co) * k * k + p];
+        std::vector<float> packed;
+        make_conv(g->l1, w.data(), k * k * c1, z_dim, 1, 1, 1, 0, 1, 1, ACT_RELU, packed, g->kpad, 0);
+        g->l1.flops_nominal = 2.0 * z_dim * c1 * k * k;
+        fold_bn(c1, t[1], t[2], t[3], t[4], t[5], sc1, sh1);
+        sc.resize((size_t)k * k * c1);
+        sh.resize(sc.size());
+        for (int p = 0; p < k * k; ++p)
+            for (int co = 0; co < c1; ++co) {
+                sc[(size_t)p * c1 + co] = sc1[co];
+                sh[(size_t)p * c1 + co] = sh1[co];
+            }
+        if ((rc = upload_conv(g->arena, g->l1, packed, sc, sh))) { delete g; return rc; }
+    }
+    {
+        std::vector<float> packed, sc, sh;
+        make_convt_k4s2p1(g->l2, t[6], c1, c2, k, k, ACT_RELU, packed);
+        fold_bn(c2, t[7], t[8], t[9], t[10], t[11], sc, sh);
+        if ((rc = upload_conv(g->arena, g->l2, packed, sc, sh))) { delete g; return rc; }
+    }
+    {
+        std::vector<float> w5((size_t)16 * c2);
+        for (int ci = 0; ci < c2; ++ci)
+            for (int p = 0; p < 16; ++p) w5[(size_t)p * c2 + ci] = t[12][(size_t)ci * 16 + p];
+        if ((rc = g->arena.upload(w5, &g->w5))) { delete g; return rc; }
+        g->b5 = t[13][0];
+    }
+    *out = g;
+    return GDPSO_OK;
+}
+
+extern "C" void gdpso_generator_destroy(gdpso_generator *g) { delete g; }
+extern "C" int gdpso_generator_image_side(const gdpso_generator *g) { return g ? g->side : 0; }
+
+extern "C" size_t gdpso_generator_workspace_bytes(const gdpso_generator *g, int n) {
+    if (!g || n <= 0) return 0;
+    ConvLayer a, b;
+    return gen_layout(g, n, a, b).total;
+}
+
+extern "C" int gdpso_generator_forward(const gdpso_generator *g, void *stream_, int n, const void *z, int z_is_f64,
+                                       float *img, float *img01, const float *target, float *mse, void *workspace,
+                                       size_t workspace_bytes) {
+    GDPSO_REQUIRE(g && z && img01 && workspace, "generator_forward: null argument");
+    GDPSO_REQUIRE(n > 0, "generator_forward: n must be positive");
+    GDPSO_REQUIRE((target == nullptr) == (mse == nullptr), "generator_forward: target and mse go together");
+    hipStream_t stream = (hipStream_t)stream_;
+    ConvLayer l1, l2;
+    const GenLayout L = gen_layout(g, n, l1, l2);
+    if (workspace_bytes < L.total) return fail(GDPSO_ERR_WORKSPACE, "generator_forward: workspace too small");
+    char *ws = (char *)workspace;
+    float *zpad = (float *)(ws + L.zpad), *a1 = (float *)(ws + L.a1), *a2 = (float *)(ws + L.a2);
+    float *sk = (float *)(ws + L.splitk);
+    const long ne = (long)n * g->kpad;
+    hipLaunchKernelGGL(latent_prep_kernel, dim3(ceil_div(ne, 256)), dim3(256), 0, stream, z, z_is_f64, n, g->z_dim, g->kpad, zpad);
+    int rc;
+    if ((rc = launch_conv(l1, stream, n, zpad, nullptr, a1, sk))) return rc;
+    if ((rc = launch_conv(l2, stream, n, a1, nullptr, a2, sk))) return rc;
+    const int hin = 2 * g->k1;
+    const size_t smem = ((size_t)16 * g->features + (size_t)g->side * g->side + 16) * sizeof(float);
+    hipLaunchKernelGGL(gen_last_kernel, dim3(n), dim3(256), smem, stream, a2, g->w5, g->b5, hin, g->features, img, img01, target, mse);
+    GDPSO_HIP(hipGetLastError());
+    return GDPSO_OK;
+}
+
+// ============================================================================= assessor
+struct Bottleneck {
+    ConvLayer c1, c2, c3, ds;
+    bool has_ds;
+};
+
+struct gdpso_assessor {
+    int n_class, side, ho, hp, stem_band;
+    const float *stem_w, *stem_scale, *stem_shift;
+    std::vector<Bottleneck> blocks;
+    const float *fc_w, *fc_b;
+    int feat_c, feat_hw;
+    double flops;
+    int num_cus;
+    DeviceArena arena;
+};
+
+namespace {
+struct AssLayout {
+    size_t x, y, t1, t2, sc, splitk, total;
+    std::vector<Bottleneck> blocks;
+};
+AssLayout ass_layout(const gdpso_assessor *a, int n) {
+    AssLayout L;
+    L.blocks = a->blocks;
+    size_t xy = (size_t)n * a->hp * a->hp * 64, t1 = 0, t2 = 0, sc = 0, sk = 0;
+    auto out_elems = [&](const ConvLayer &c) { return (size_t)n * c.hout * c.wout * c.cout; };
+    for (auto &b : L.blocks) {
+        plan_conv(b.c1, n, a->num_cus);
+        plan_conv(b.c2, n, a->num_cus);
+        plan_conv(b.c3, n, a->num_cus);
+        t1 = std::max(t1, out_elems(b.c1));
+        t2 = std::max(t2, out_elems(b.c2));
+        xy = std::max(xy, out_elems(b.c3));
+        sk = std::max({sk, conv_splitk_bytes(b.c1, n), conv_splitk_bytes(b.c2, n), conv_splitk_bytes(b.c3, n)});
+        if (b.has_ds) {
+            plan_conv(b.ds, n, a->num_cus);
+            sc = std::max(sc, out_elems(b.ds));
+            sk = std::max(sk, conv_splitk_bytes(b.ds, n));
+        }
+    }
+    size_t off = 0;
+    L.x = off; off += align_up(xy * 4);
+    L.y = off; off += align_up(xy * 4);
+    L.t1 = off; off += align_up(t1 * 4);
+    L.t2 = off; off += align_up(t2 * 4);
+    L.sc = off; off += align_up(sc * 4);
+    L.splitk = off; off += align_up(sk);
+    L.total = off;
+    return L;
+}
+}  // namespace
+
+extern "C" int gdpso_assessor_create_resnet(gdpso_assessor **out, const int depths[4], int n_class, int img_side,
+                                            const float *const *t, int n_tensors) {
+    GDPSO_REQUIRE(out && depths && t, "assessor_create: null argument");
+    GDPSO_REQUIRE(n_class >= 2 && n_class <= MAX_CLASSES, "assessor_create: n_class must be in [2, 64]");
+    GDPSO_REQUIRE(img_side >= 8 && img_side <= 64, "assessor_create: img_side must be in [8, 64]");
+    int expect = 5 + 2;
+    for (int s = 0; s < 4; ++s) {
+        GDPSO_REQUIRE(depths[s] >= 1, "assessor_create: every stage needs at least one block");
+        expect += depths[s] * 15 + 5;
+    }
+    GDPSO_REQUIRE(n_tensors == expect, "assessor_create: wrong number of tensors for these depths");
+    auto a = new gdpso_assessor();
+    a->n_class = n_class;
+    a->side = img_side;
+    a->ho = (img_side + 6 - 7) / 2 + 1;
+    a->hp = (a->ho + 2 - 3) / 2 + 1;
+    a->num_cus = device_cus();
+    // pooled rows per stem workgroup: conv rows of the band must fit 64 KiB of LDS
+    {
+        const size_t row_bytes = (size_t)a->ho * 64 * 4;
+        const size_t avail = (size_t)64 * 1024 - (size_t)(img_side + 6) * (img_side + 6) * 4;
+        const int max_rows = (int)std::max<size_t>(3, avail / row_bytes);
+        a->stem_band = std::max(1, std::min(a->hp, (max_rows - 1) / 2));
+    }
+    int rc, ti = 0;
+    {
+        std::vector<float> w((size_t)49 * 64), sc, sh;
+        for (int co = 0; co < 64; ++co)
+            for (int p = 0; p < 49; ++p) w[(size_t)p * 64 + co] = t[0][(size_t)co * 49 + p];
+        fold_bn(64, nullptr, t[1], t[2], t[3], t[4], sc, sh);
+        if ((rc = a->arena.upload(w, &a->stem_w)) || (rc = a->arena.upload(sc, &a->stem_scale)) ||
+            (rc = a->arena.upload(sh, &a->stem_shift))) { delete a; return rc; }
+        ti = 5;
+        a->flops = 2.0 * a->ho * a->ho * 64 * 49;
+    }
+    int cin = 64, h = a->hp;
+    for (int s = 0; s < 4; ++s) {
+        const int mid = 64 << s;
+        for (int b = 0; b < depths[s]; ++b) {
+            const int stride = (b == 0 && s > 0) ? 2 : 1;
+            Bottleneck blk;
+            std::memset(&blk, 0, sizeof(blk));
+            std::vector<float> packed, sc, sh;
+            make_conv(blk.c1, t[ti], mid, cin, 1, 1, 1, 0, h, h, ACT_RELU, packed);
+            fold_bn(mid, nullptr, t[ti + 1], t[ti + 2], t[ti + 3], t[ti + 4], sc, sh);
+            if ((rc = upload_conv(a->arena, blk.c1, packed, sc, sh))) { delete a; return rc; }
+            make_conv(blk.c2, t[ti + 5], mid, mid, 3, 3, stride, 1, h, h, ACT_RELU, packed);
+            fold_bn(mid, nullptr, t[ti + 6], t[ti + 7], t[ti + 8], t[ti + 9], sc, sh);
+            if ((rc = upload_conv(a->arena, blk.c2, packed, sc, sh))) { delete a; return rc; }
+            const int h2 = blk.c2.hout;
+            make_conv(blk.c3, t[ti + 10], mid * 4, mid, 1, 1, 1, 0, h2, h2, ACT_RELU, packed);  // ReLU after the residual add
+            fold_bn(mid * 4, nullptr, t[ti + 11], t[ti + 12], t[ti + 13], t[ti + 14], sc, sh);
+            if ((rc = upload_conv(a->arena, blk.c3, packed, sc, sh))) { delete a; return rc; }
+            ti += 15;
+            blk.has_ds = (b == 0);
+            a->flops += blk.c1.flops_nominal + blk.c2.flops_nominal + blk.c3.flops_nominal;
+            if (blk.has_ds) {
+                make_conv(blk.ds, t[ti], mid * 4, cin, 1, 1, stride, 0, h, h, ACT_NONE, packed);
+                fold_bn(mid * 4, nullptr, t[ti + 1], t[ti + 2], t[ti + 3], t[ti + 4], sc, sh);
+                if ((rc = upload_conv(a->arena, blk.ds, packed, sc, sh))) { delete a; return rc; }
+                ti += 5;
+                a->flops += blk.ds.flops_nominal;
+            }
+            a->blocks.push_back(blk);
+            cin = mid * 4;
+            h = h2;
+        }
+    }
+    a->feat_c = cin;
+    a->feat_hw = h * h;
+    {
+        std::vector<float> w(t[ti], t[ti] + (size_t)n_class * cin), b(t[ti + 1], t[ti + 1] + n_class);
+        if ((rc = a->arena.upload(w, &a->fc_w)) || (rc = a->arena.upload(b, &a->fc_b))) { delete a; return rc; }
+        a->flops += 2.0 * cin * n_class;
+    }
+    *out = a;
+    return GDPSO_OK;
+}
+
+extern "C" void gdpso_assessor_destroy(gdpso_assessor *a) { delete a; }
+extern "C" int gdpso_assessor_n_class(const gdpso_assessor *a) { return a ? a->n_class : 0; }
+extern "C" double gdpso_assessor_flops_per_image(const gdpso_assessor *a) { return a ? a->flops : 0.0; }
+extern "C" size_t gdpso_assessor_workspace_bytes(const gdpso_assessor *a, int n) {
+    if (!a || n <= 0) return 0;
+    return ass_layout(a, n).total;
+}
+
+extern "C" int gdpso_assessor_forward(const gdpso_assessor *a, void *stream_, int n, const float *img01, float *logits,
+                                      float *fitness, int class_index, int mode, float threshold, float eps,
+                                      const float *mse, float w_ass, float w_rec, void *workspace, size_t workspace_bytes) {
+    GDPSO_REQUIRE(a && img01 && workspace, "assessor_forward: null argument");
+    GDPSO_REQUIRE(n > 0, "assessor_forward: n must be positive");
+    GDPSO_REQUIRE(logits || fitness, "assessor_forward: nothing to compute");
+    GDPSO_REQUIRE(mode == GDPSO_MODE_IN_TRAINING || mode == GDPSO_MODE_OUT_TRAINING, "assessor_forward: unknown fitness mode");
+    GDPSO_REQUIRE(!fitness || a->n_class == 2 || (class_index >= 0 && class_index < a->n_class), "assessor_forward: class_index out of range");
+    hipStream_t stream = (hipStream_t)stream_;
+    const AssLayout L = ass_layout(a, n);
+    if (workspace_bytes < L.total) return fail(GDPSO_ERR_WORKSPACE, "assessor_forward: workspace too small");
+    char *ws = (char *)workspace;
+    float *x = (float *)(ws + L.x), *y = (float *)(ws + L.y), *t1 = (float *)(ws + L.t1), *t2 = (float *)(ws + L.t2);
+    float *sc = (float *)(ws + L.sc), *sk = (float *)(ws + L.splitk);
+    {
+        const int rows = 2 * a->stem_band + 1;
+        const size_t smem = ((size_t)(a->side + 6) * (a->side + 6) + (size_t)rows * a->ho * 64) * sizeof(float);
+        dim3 grid(n, ceil_div(a->hp, a->stem_band));
+        hipLaunchKernelGGL(stem_kernel, grid, dim3(256), smem, stream, img01, a->stem_w, a->stem_scale, a->stem_shift, a->side,
+                           a->ho, a->hp, a->stem_band, x);
+    }
+    int rc;
+    for (const Bottleneck &b : L.blocks) {
+        if ((rc = launch_conv(b.c1, stream, n, x, nullptr, t1, sk))) return rc;
+        if ((rc = launch_conv(b.c2, stream, n, t1, nullptr, t2, sk))) return rc;
+        const float *res = x;
+        if (b.has_ds) {
+            if ((rc = launch_conv(b.ds, stream, n, x, nullptr, sc, sk))) return rc;
+            res = sc;
+        }
+        if ((rc = launch_conv(b.c3, stream, n, t2, res, y, sk))) return rc;
+        std::swap(x, y);
+    }
+    hipLaunchKernelGGL(head_kernel, dim3(n), dim3(256), 0, stream, x, a->feat_hw, a->feat_c, a->fc_w, a->fc_b, a->n_class, logits,
+                       fitness, class_index, mode, threshold, eps, mse, w_ass, w_rec);
+    GDPSO_HIP(hipGetLastError());
+    return GDPSO_OK;
+}
+
+// ============================================================================== encoder
+struct gdpso_encoder {
+    int enc_dim, features, out_pad;
+    const float *w1, *b1;
+    ConvLayer c2, c3;
+    int num_cus;
+    DeviceArena arena;
+};
+
+namespace {
+struct EncLayout {
+    size_t a1, a2, lat, splitk, total;
+};
+EncLayout enc_layout(const gdpso_encoder *e, int n, ConvLayer &c2, ConvLayer &c3) {
+    c2 = e->c2;
+    c3 = e->c3;
+    plan_conv(c2, n, e->num_cus);
+    plan_conv(c3, n, e->num_cus);
+    EncLayout L;
+    size_t off = 0;
+    L.a1 = off; off += align_up((size_t)n * 14 * 14 * e->features * 4);
+    L.a2 = off; off += align_up((size_t)n * 7 * 7 * 2 * e->features * 4);
+    L.lat = off; off += align_up((size_t)n * e->out_pad * 4);
+    L.splitk = off; off += align_up(std::max(conv_splitk_bytes(c2, n), conv_splitk_bytes(c3, n)));
+    L.total = off;
+    return L;
+}
+}  // namespace
+
+extern "C" int gdpso_encoder_create(gdpso_encoder **out, int enc_dim, int features_e, const float *const *t, int n_tensors) {
+    GDPSO_REQUIRE(out && t, "encoder_create: null argument");
+    GDPSO_REQUIRE(n_tensors == 6, "encoder_create: expected 6 tensors");
+    GDPSO_REQUIRE(enc_dim > 0 && features_e >= 32 && features_e % 32 == 0, "encoder_create: features_e must be a multiple of 32");
+    auto e = new gdpso_encoder();
+    e->enc_dim = enc_dim;
+    e->features = features_e;
+    e->out_pad = (enc_dim + 63) / 64 * 64;
+    e->num_cus = device_cus();
+    const int c1 = features_e, c2 = 2 * features_e;
+    int rc;
+    std::vector<float> w1((size_t)16 * c1), b1(t[1], t[1] + c1);
+    for (int co = 0; co < c1; ++co)
+        for (int p = 0; p < 16; ++p) w1[(size_t)p * c1 + co] = t[0][(size_t)co * 16 + p];
+    if ((rc = e->arena.upload(w1, &e->w1)) || (rc = e->arena.upload(b1, &e->b1))) { delete e; return rc; }
+    std::vector<float> packed, ones, bias;
+    make_conv(e->c2, t[2], c2, c1, 4, 4, 2, 1, 14, 14, ACT_LEAKY02, packed);
+    ones.assign(c2, 1.f);
+    bias.assign(t[3], t[3] + c2);
+    if ((rc = upload_conv(e->arena, e->c2, packed, ones, bias))) { delete e; return rc; }
+    make_conv(e->c3, t[4], enc_dim, c2, 7, 7, 2, 0, 7, 7, ACT_NONE, packed, 0, e->out_pad);
+    ones.assign(e->out_pad, 1.f);
+    bias.assign(e->out_pad, 0.f);
+    std::copy(t[5], t[5] + enc_dim, bias.begin());
+    if ((rc = upload_conv(e->arena, e->c3, packed, ones, bias))) { delete e; return rc; }
+    *out = e;
+    return GDPSO_OK;
+}
+
+extern "C" void gdpso_encoder_destroy(gdpso_encoder *e) { delete e; }
+extern "C" size_t gdpso_encoder_workspace_bytes(const gdpso_encoder *e, int n) {
+    if (!e || n <= 0) return 0;
+    ConvLayer a, b;
+    return enc_layout(e, n, a, b).total;
+}
+
+extern "C" int gdpso_encoder_forward(const gdpso_encoder *e, void *stream_, int n, const float *img, float *latent,
+                                     void *workspace, size_t workspace_bytes) {
+    GDPSO_REQUIRE(e && img && latent && workspace, "encoder_forward: null argument");
+    GDPSO_REQUIRE(n > 0, "encoder_forward: n must be positive");
+    hipStream_t stream = (hipStream_t)stream_;
+    ConvLayer c2, c3;
+    const EncLayout L = enc_layout(e, n, c2, c3);
+    if (workspace_bytes < L.total) return fail(GDPSO_ERR_WORKSPACE, "encoder_forward: workspace too small");
+    char *ws = (char *)workspace;
+    float *a1 = (float *)(ws + L.a1), *a2 = (float *)(ws + L.a2), *lat = (float *)(ws + L.lat), *sk = (float *)(ws + L.splitk);
+    hipLaunchKernelGGL(enc_first_kernel, dim3(n), dim3(256), 30 * 30 * sizeof(float), stream, img, e->w1, e->b1, 28, 14, e->features, a1);
+    int rc;
+    if ((rc = launch_conv(c2, stream, n, a1, nullptr, a2, sk))) return rc;
+    if ((rc = launch_conv(c3, stream, n, a2, nullptr, lat, sk))) return rc;
+    hipLaunchKernelGGL(slice_cols_kernel, dim3(ceil_div((long)n * e->enc_dim, 256)), dim3(256), 0, stream, lat, e->out_pad, n,
+                       e->enc_dim, latent);
+    GDPSO_HIP(hipGetLastError());
+    return GDPSO_OK;
+}

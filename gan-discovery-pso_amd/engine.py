@@ -1,0 +1,442 @@
+"""Device-resident swarm engine: owns the HIP handles and buffers and drives the loop.
+
+Layering (top to bottom):
+
+* ``pso/util_pso.Swarm`` / ``pso/util_discovery.Discovery`` -- the reference's Python
+  interface (reference src/pso/util_pso.py, src/pso/util_discovery.py);
+* this module -- weight extraction from ``state_dict`` layouts, buffer ownership, the
+  single-GPU fused loop and the sharded multi-GPU loop (one collective per iteration);
+* ``_lib`` -- ctypes binding of the C ABI (include/gdpso.h) of libgdpso.so, where all the
+  arithmetic happens in HIP kernels.
+
+PyTorch is used for device memory, streams and ``torch.distributed`` only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, ptr
+
+BN_FIELDS = ("weight", "bias", "running_mean", "running_var")
+
+
+def _np(sd, key):
+    v = sd[key]
+    if isinstance(v, torch.Tensor):
+        v = v.detach().cpu().numpy()
+    return np.ascontiguousarray(v, dtype=np.float32)
+
+
+# ------------------------------------------------------------------ state_dict readers
+def generator_tensors(sd):
+    """The 14 arrays gdpso_generator_create wants, from the generator's state_dict keys
+    (reference src/utils/util_dcgan.py:133-139: gen.0.0, gen.0.1, gen.1.0, gen.1.1, gen.2)."""
+    keys = ["gen.0.0.weight", "gen.0.0.bias"] + [f"gen.0.1.{f}" for f in BN_FIELDS]
+    keys += ["gen.1.0.weight", "gen.1.0.bias"] + [f"gen.1.1.{f}" for f in BN_FIELDS]
+    keys += ["gen.2.weight", "gen.2.bias"]
+    t = [_np(sd, k) for k in keys]
+    z_dim, c1, k, _ = t[0].shape
+    if t[12].shape[1] != 1:
+        raise ValueError("only single-channel generators are supported (data.channel = 1)")
+    return t, dict(z_dim=int(z_dim), features_g=int(c1 // 2), first_kernel=int(k))
+
+
+def resnet_tensors(sd):
+    """Arrays in the forward order gdpso_assessor_create_resnet wants, plus the depths and
+    class count read off the keys (reference src/pso/util_cnn.py:81-190)."""
+    t = [_np(sd, "conv1.weight")] + [_np(sd, f"bn1.{f}") for f in BN_FIELDS]
+    if t[0].shape[1] != 1:
+        raise ValueError("only single-channel assessors are supported (data.channel = 1)")
+    depths = []
+    for li in range(1, 5):
+        b = 0
+        while f"layer{li}.{b}.conv1.weight" in sd:
+            p = f"layer{li}.{b}"
+            for c in (1, 2, 3):
+                t.append(_np(sd, f"{p}.conv{c}.weight"))
+                t += [_np(sd, f"{p}.bn{c}.{f}") for f in BN_FIELDS]
+            if b == 0:
+                t.append(_np(sd, f"{p}.identity_downsample.0.weight"))
+                t += [_np(sd, f"{p}.identity_downsample.1.{f}") for f in BN_FIELDS]
+            b += 1
+        depths.append(b)
+    t += [_np(sd, "fc.weight"), _np(sd, "fc.bias")]
+    return t, dict(depths=tuple(depths), n_class=int(t[-1].shape[0]))
+
+
+def encoder_tensors(sd):
+    """reference src/inverter/utils_ae/util_inverter.py:168-174: enc.0, enc.2.0, enc.3."""
+    keys = ["enc.0.weight", "enc.0.bias", "enc.2.0.weight", "enc.2.0.bias", "enc.3.weight", "enc.3.bias"]
+    t = [_np(sd, k) for k in keys]
+    return t, dict(enc_dim=int(t[4].shape[0]), features_e=int(t[0].shape[0]))
+
+
+def _state_dict_of(model):
+    return model if isinstance(model, dict) else model.state_dict()
+
+
+# ---------------------------------------------------------------------------- handles
+class _Handle:
+    _destroy = None
+
+    def __init__(self):
+        self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            if self.h and self._destroy:
+                getattr(_lib.lib(), self._destroy)(self.h)
+                self.h = C.c_void_p()
+        except Exception:
+            pass
+
+
+def _device_guard(device):
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise _lib.GdpsoError(f"the PSO hot path runs on an MI355X only (got device '{device}'); there is no CPU fallback")
+    return device
+
+
+class PackedGenerator(_Handle):
+    """Generator weights repacked on the device (gdpso_generator_create)."""
+    _destroy = "gdpso_generator_destroy"
+
+    def __init__(self, model, device):
+        super().__init__()
+        self.device = _device_guard(device)
+        tensors, self.meta = generator_tensors(_state_dict_of(model))
+        arr, keep = _lib.host_float_pointers(tensors)
+        with torch.cuda.device(self.device):
+            check(_lib.lib().gdpso_generator_create(C.byref(self.h), self.meta["z_dim"], self.meta["features_g"],
+                                                    self.meta["first_kernel"], arr, len(keep)))
+        self.z_dim = self.meta["z_dim"]
+        self.side = _lib.lib().gdpso_generator_image_side(self.h)
+        # nominal MACs x2: ConvT(z->2F,k) + ConvT(2F->F,k4s2: 4 taps/output) + ConvT(F->1)
+        f, k = self.meta["features_g"], self.meta["first_kernel"]
+        self.flops_per_image = 2.0 * (self.z_dim * 2 * f * k * k + (2 * k) ** 2 * f * 2 * f * 4 + (4 * k) ** 2 * f * 4)
+
+    def workspace_bytes(self, n):
+        return _lib.lib().gdpso_generator_workspace_bytes(self.h, n)
+
+
+class PackedAssessor(_Handle):
+    """ResNet assessor weights repacked on the device (gdpso_assessor_create_resnet)."""
+    _destroy = "gdpso_assessor_destroy"
+
+    def __init__(self, model, device, img_side=28):
+        super().__init__()
+        self.device = _device_guard(device)
+        tensors, self.meta = resnet_tensors(_state_dict_of(model))
+        arr, keep = _lib.host_float_pointers(tensors)
+        depths = (C.c_int * 4)(*self.meta["depths"])
+        with torch.cuda.device(self.device):
+            check(_lib.lib().gdpso_assessor_create_resnet(C.byref(self.h), depths, self.meta["n_class"], img_side, arr, len(keep)))
+        self.n_class = self.meta["n_class"]
+        self.side = img_side
+        self.flops_per_image = _lib.lib().gdpso_assessor_flops_per_image(self.h)
+
+    def workspace_bytes(self, n):
+        return _lib.lib().gdpso_assessor_workspace_bytes(self.h, n)
+
+
+class PackedEncoder(_Handle):
+    """Inverter encoder repacked on the device (gdpso_encoder_create)."""
+    _destroy = "gdpso_encoder_destroy"
+
+    def __init__(self, model, device):
+        super().__init__()
+        self.device = _device_guard(device)
+        tensors, self.meta = encoder_tensors(_state_dict_of(model))
+        arr, keep = _lib.host_float_pointers(tensors)
+        with torch.cuda.device(self.device):
+            check(_lib.lib().gdpso_encoder_create(C.byref(self.h), self.meta["enc_dim"], self.meta["features_e"], arr, len(keep)))
+        self.enc_dim = self.meta["enc_dim"]
+
+    def forward(self, img: torch.Tensor) -> torch.Tensor:
+        """img [n,1,28,28] or [n,28,28] fp32 on the device -> latent [n, enc_dim, 1, 1]."""
+        n = img.shape[0]
+        x = img.to(self.device, torch.float32).reshape(n, 28, 28).contiguous()
+        ws = torch.empty(_lib.lib().gdpso_encoder_workspace_bytes(self.h, n), dtype=torch.uint8, device=self.device)
+        out = torch.empty(n, self.enc_dim, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(_lib.lib().gdpso_encoder_forward(self.h, _lib.stream_handle(self.device), n, ptr(x), ptr(out), ptr(ws), ws.numel()))
+        return out.reshape(n, self.enc_dim, 1, 1)
+
+
+# -------------------------------------------------------------------- fitness settings
+@dataclass
+class FitnessSpec:
+    class_index: int = 1
+    mode: str = "optimize_out_training"
+    threshold: float = 0.0
+    eps: float = 0.1
+    w_ass: float = 1.0
+    w_rec: float = 1.0
+
+    def mode_code(self) -> int:
+        if self.mode == "optimize_in_training":
+            return _lib.MODE_IN_TRAINING
+        if self.mode == "optimize_out_training":
+            return _lib.MODE_OUT_TRAINING
+        raise ValueError(self.mode)  # same error as reference util_discovery.py:80
+
+
+class Evaluator:
+    """latents -> images -> fitness on the device (generator + assessor handles + workspace)."""
+
+    def __init__(self, gen: PackedGenerator, ass: PackedAssessor):
+        if gen.side != ass.side:
+            raise ValueError(f"generator makes {gen.side}x{gen.side} images but the assessor plan is for {ass.side}")
+        self.gen, self.ass, self.device = gen, ass, gen.device
+        self._ws = None
+        self._img = {}
+
+    def workspace(self, n):
+        need = max(self.gen.workspace_bytes(n), self.ass.workspace_bytes(n))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def image_buffers(self, n):
+        if n not in self._img:
+            s = self.gen.side
+            self._img[n] = (torch.empty(n, s, s, dtype=torch.float32, device=self.device),
+                            torch.empty(n, s, s, dtype=torch.float32, device=self.device),
+                            torch.empty(n, dtype=torch.float32, device=self.device))
+        return self._img[n]
+
+    def images(self, z: torch.Tensor, target=None):
+        """z [n,Z] float64/float32 device tensor -> (img01, img, mse|None), each [n,S,S]."""
+        n = z.shape[0]
+        img, img01, mse = self.image_buffers(n)
+        ws = self.workspace(n)
+        with torch.cuda.device(self.device):
+            check(_lib.lib().gdpso_generator_forward(self.gen.h, _lib.stream_handle(self.device), n, ptr(z),
+                                                     1 if z.dtype == torch.float64 else 0, ptr(img), ptr(img01),
+                                                     ptr(target), ptr(mse) if target is not None else 0, ptr(ws), ws.numel()))
+        return img01, img, (mse if target is not None else None)
+
+    def assess(self, img01: torch.Tensor, spec: FitnessSpec, mse=None, want_logits=False):
+        n = img01.shape[0]
+        ws = self.workspace(n)
+        fit = torch.empty(n, dtype=torch.float32, device=self.device)
+        logits = torch.empty(n, self.ass.n_class, dtype=torch.float32, device=self.device) if want_logits else None
+        with torch.cuda.device(self.device):
+            check(_lib.lib().gdpso_assessor_forward(self.ass.h, _lib.stream_handle(self.device), n, ptr(img01), ptr(logits), ptr(fit),
+                                                    spec.class_index, spec.mode_code(), spec.threshold, spec.eps, ptr(mse),
+                                                    spec.w_ass, spec.w_rec, ptr(ws), ws.numel()))
+        return fit, logits
+
+    def fitness(self, z: torch.Tensor, spec: FitnessSpec, target=None):
+        img01, img, mse = self.images(z, target)
+        fit, _ = self.assess(img01, spec, mse)
+        return fit, img01, img
+
+
+# ------------------------------------------------------------------------ swarm state
+class HipSwarm:
+    """Swarm state in HBM (structure of arrays, float64 like the reference's numpy state)
+    and the per-phase kernel launches.  One instance per process / GPU."""
+
+    def __init__(self, evaluator: Evaluator, n_local, d, max_iter, *, first_index=0, n_ranks=1, rank=0, n_global=None,
+                 history=True, diagnostics=True):
+        self.ev, self.device = evaluator, evaluator.device
+        self.n, self.d, self.max_iter = int(n_local), int(d), int(max_iter)
+        self.first_index, self.n_ranks, self.rank = int(first_index), int(n_ranks), int(rank)
+        self.n_global = int(n_global if n_global is not None else n_local)
+        if evaluator.gen.z_dim != self.d:
+            raise ValueError(f"dim_space {d} != generator z_dim {evaluator.gen.z_dim}")
+        dev, f64, f32 = self.device, torch.float64, torch.float32
+        n, t = self.n, self.max_iter
+        self.pos = torch.zeros(n, d, dtype=f64, device=dev)
+        self.vel = torch.zeros(n, d, dtype=f64, device=dev)
+        self.pbest_pos = torch.zeros(n, d, dtype=f64, device=dev)
+        self.pbest_val = torch.zeros(n, dtype=f32, device=dev)
+        self.fitness = torch.zeros(n, dtype=f32, device=dev)
+        self.gbest_pos = torch.zeros(d, dtype=f64, device=dev)
+        self.ctrl = torch.zeros(_lib.CTRL_DOUBLES, dtype=f64, device=dev)
+        self.g_best_val = torch.zeros(t + 1, dtype=f32, device=dev)
+        self.g_best_val_dummy = torch.zeros(t, dtype=f32, device=dev)
+        self.mean_dist = torch.zeros(t, dtype=f64, device=dev) if diagnostics else None
+        self.hist_pos = torch.zeros(t + 1, n, d, dtype=f64, device=dev) if history else None
+        self.hist_vel = torch.zeros(t + 1, n, d, dtype=f64, device=dev) if history else None
+        self.cand = torch.zeros(self.n_ranks, d + 2, dtype=f64, device=dev)
+        nscr = max(self.n_global, n) if diagnostics else n
+        self.scratch = torch.zeros(_lib.lib().gdpso_swarm_scratch_bytes(nscr), dtype=torch.uint8, device=dev)
+        self.fit_hist = torch.zeros(t, n, dtype=f32, device=dev) if history else None
+        self.rand = None
+        self.target = None
+        self.desc = _lib.SwarmDesc(
+            n=n, d=d, first_index=self.first_index, n_ranks=self.n_ranks, pos=ptr(self.pos), vel=ptr(self.vel),
+            pbest_pos=ptr(self.pbest_pos), pbest_val=ptr(self.pbest_val), fitness=ptr(self.fitness),
+            gbest_pos=ptr(self.gbest_pos), ctrl=ptr(self.ctrl), g_best_val=ptr(self.g_best_val),
+            g_best_val_dummy=ptr(self.g_best_val_dummy), mean_dist=ptr(self.mean_dist), hist_pos=ptr(self.hist_pos),
+            hist_vel=ptr(self.hist_vel), cand=ptr(self.cand), scratch=ptr(self.scratch), scratch_bytes=self.scratch.numel(),
+            max_iter=t)
+
+    # -- set-up
+    def _stream(self):
+        return _lib.stream_handle(self.device)
+
+    def load(self, pos: np.ndarray, vel: np.ndarray, w_inertia: float, rand=None, target=None):
+        self.pos.copy_(torch.from_numpy(np.ascontiguousarray(pos, dtype=np.float64)))
+        self.vel.copy_(torch.from_numpy(np.ascontiguousarray(vel, dtype=np.float64)))
+        self.rand = None if rand is None else torch.from_numpy(np.ascontiguousarray(rand, dtype=np.float64)).to(self.device)
+        self.target = None if target is None else target.to(self.device, torch.float32).reshape(self.n, self.ev.gen.side, self.ev.gen.side).contiguous()
+        with torch.cuda.device(self.device):
+            check(_lib.lib().gdpso_swarm_reset(C.byref(self.desc), self._stream(), float(w_inertia)))
+
+    # -- phases (multi-process loop)
+    def evaluate(self, i, spec: FitnessSpec):
+        img, img01, mse = self.ev.image_buffers(self.n)
+        ws = self.ev.workspace(self.n)
+        L, s = _lib.lib(), self._stream()
+        with torch.cuda.device(self.device):
+            check(L.gdpso_generator_forward(self.ev.gen.h, s, self.n, ptr(self.pos), 1, ptr(img), ptr(img01), ptr(self.target),
+                                            ptr(mse) if self.target is not None else 0, ptr(ws), ws.numel()))
+            check(L.gdpso_assessor_forward(self.ev.ass.h, s, self.n, ptr(img01), 0, ptr(self.fitness), spec.class_index,
+                                           spec.mode_code(), spec.threshold, spec.eps, ptr(mse) if self.target is not None else 0,
+                                           spec.w_ass, spec.w_rec, ptr(ws), ws.numel()))
+        if self.fit_hist is not None:
+            self.fit_hist[i - 1].copy_(self.fitness)
+
+    def local_best(self, i):
+        with torch.cuda.device(self.device):
+            check(_lib.lib().gdpso_swarm_local_best(C.byref(self.desc), self._stream(), i, self.rank))
+
+    def global_best(self, i, schedule_inertia, early_stopping, tolerance):
+        with torch.cuda.device(self.device):
+            check(_lib.lib().gdpso_swarm_global_best(C.byref(self.desc), self._stream(), i, int(schedule_inertia),
+                                                     int(early_stopping), float(tolerance)))
+
+    def move(self, i, w_cogn, w_soci, seed=0):
+        rnd = 0 if self.rand is None else self.rand[i - 1].data_ptr()
+        with torch.cuda.device(self.device):
+            check(_lib.lib().gdpso_swarm_move(C.byref(self.desc), self._stream(), i, float(w_cogn), float(w_soci), rnd, int(seed)))
+
+    def mean_distance(self, i, pos_all: torch.Tensor):
+        with torch.cuda.device(self.device):
+            check(_lib.lib().gdpso_swarm_mean_distance(C.byref(self.desc), self._stream(), i, ptr(pos_all), pos_all.shape[0]))
+
+    # -- fused loop (one process)
+    def iterate(self, first, count, spec: FitnessSpec, w_cogn, w_soci, schedule_inertia, early_stopping, tolerance,
+                diagnostics, seed=0):
+        img, img01, mse = self.ev.image_buffers(self.n)
+        ws = self.ev.workspace(self.n)
+        run = _lib.RunDesc(class_index=spec.class_index, mode=spec.mode_code(), threshold=spec.threshold, eps=spec.eps,
+                           target=ptr(self.target), w_ass=spec.w_ass, w_rec=spec.w_rec, w_cogn=w_cogn, w_soci=w_soci,
+                           schedule_inertia=int(schedule_inertia), early_stopping=int(early_stopping), tolerance=tolerance,
+                           rand=ptr(self.rand), seed=int(seed), diagnostics=int(bool(diagnostics) and self.mean_dist is not None),
+                           img01=ptr(img01), img=ptr(img), mse=ptr(mse), workspace=ptr(ws), workspace_bytes=ws.numel())
+        with torch.cuda.device(self.device):
+            if self.fit_hist is None:
+                check(_lib.lib().gdpso_swarm_iterate(C.byref(self.desc), self.ev.gen.h, self.ev.ass.h, C.byref(run),
+                                                     self._stream(), first, count))
+            else:  # keep every iteration's fitness: one iteration per call, device-side copy in between
+                for i in range(first, first + count):
+                    check(_lib.lib().gdpso_swarm_iterate(C.byref(self.desc), self.ev.gen.h, self.ev.ass.h, C.byref(run),
+                                                         self._stream(), i, 1))
+                    self.fit_hist[i - 1].copy_(self.fitness)
+
+    # -- read-back
+    def control(self) -> np.ndarray:
+        return self.ctrl.cpu().numpy()
+
+    def results(self) -> dict:
+        """Everything the reference's Swarm exposes after optimize(), as numpy arrays."""
+        c = self.control()
+        stop = int(c[_lib.CTRL_STOP_ITER])
+        done = int(c[_lib.CTRL_ITERS_DONE])
+        iters = stop if stop else done
+        out = dict(iters=iters, stopped=bool(stop), w_inertia=float(c[_lib.CTRL_W]),
+                   gbest_val=np.float32(c[_lib.CTRL_GBEST_VAL]), gbest_idx=int(c[_lib.CTRL_GBEST_IDX]),
+                   g_best_val=self.g_best_val[:int(c[_lib.CTRL_N_IMPROVE])].cpu().numpy(),
+                   g_best_val_dummy=self.g_best_val_dummy[:iters].cpu().numpy(),
+                   g_best_pos=self.gbest_pos.cpu().numpy(), pos=self.pos.cpu().numpy(), vel=self.vel.cpu().numpy(),
+                   pbest_pos=self.pbest_pos.cpu().numpy(), pbest_val=self.pbest_val.cpu().numpy())
+        if self.mean_dist is not None:
+            out["mean_mse"] = self.mean_dist[:iters].cpu().numpy()
+        if self.hist_pos is not None:
+            out["hist_pos"] = self.hist_pos[:iters + 1].cpu().numpy()
+            out["hist_vel"] = self.hist_vel[:iters + 1].cpu().numpy()
+            out["fitness"] = self.fit_hist[:iters].cpu().numpy()
+        return out
+
+
+# -------------------------------------------------------------------------- the loops
+def shard_bounds(n_global: int, n_ranks: int, rank: int):
+    """Contiguous particle blocks: rank r owns [lo, hi); the first n % W ranks get one more."""
+    base, extra = divmod(n_global, n_ranks)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def run_loop(swarm, n_iterations, spec, w_cogn, w_soci, *, schedule_inertia=False, early_stopping=True, tolerance=1e-4,
+             diagnostics=True, seed=0, comm=None, poll_every=8):
+    """The while-loop of reference src/pso/util_pso.py:174-189.
+
+    ``swarm`` is a HipSwarm (or, in the CPU tests of the sharded protocol, an object with
+    the same phase methods).  With ``comm`` (a torch.distributed process group wrapper with
+    ``all_gather(out, inp)``) particles are sharded over ranks and the only exchange per
+    iteration is the all-gather of one {value, index, position} record per rank; the
+    optional diagnostic gathers positions as well.  Nothing here synchronises with the
+    device except the periodic early-stop poll.
+    """
+    if comm is None or swarm.n_ranks == 1:
+        i = 1
+        while i <= n_iterations:
+            chunk = min(poll_every, n_iterations - i + 1) if early_stopping else n_iterations - i + 1
+            swarm.iterate(i, chunk, spec, w_cogn, w_soci, schedule_inertia, early_stopping, tolerance, diagnostics, seed)
+            i += chunk
+            if early_stopping and i <= n_iterations and int(swarm.control()[_lib.CTRL_STOP_ITER]):
+                break
+        return
+    for i in range(1, n_iterations + 1):
+        swarm.evaluate(i, spec)
+        swarm.local_best(i)
+        comm.all_gather(swarm.cand, swarm.cand[swarm.rank])
+        swarm.global_best(i, schedule_inertia, early_stopping, tolerance)
+        swarm.move(i, w_cogn, w_soci, seed)
+        if diagnostics:
+            swarm.mean_distance(i, comm.gather_positions(swarm.pos, swarm.n_global))
+        if early_stopping and i % poll_every == 0 and int(swarm.control()[_lib.CTRL_STOP_ITER]):
+            break
+
+
+class TorchComm:
+    """torch.distributed plumbing for the sharded loop ("nccl" is RCCL on ROCm; "gloo" in CPU tests)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+    def all_gather(self, out: torch.Tensor, inp: torch.Tensor):
+        # out [W, d+2] is the swarm's candidate table; inp is this rank's row of it
+        self.dist.all_gather_into_tensor(out, inp.clone(), group=self.group)
+
+    def gather_positions(self, pos: torch.Tensor, n_global: int) -> torch.Tensor:
+        n_max = -(-n_global // self.world)
+        pad = torch.zeros(n_max, pos.shape[1], dtype=pos.dtype, device=pos.device)
+        pad[:pos.shape[0]] = pos
+        allp = torch.empty(self.world * n_max, pos.shape[1], dtype=pos.dtype, device=pos.device)
+        self.dist.all_gather_into_tensor(allp, pad, group=self.group)
+        if n_global == self.world * n_max:
+            return allp
+        rows = []
+        for r in range(self.world):
+            lo, hi = shard_bounds(n_global, self.world, r)
+            rows.append(allp[r * n_max:r * n_max + (hi - lo)])
+        return torch.cat(rows).contiguous()
+
+    def gather_rows(self, local: np.ndarray, axis: int, n_global: int) -> np.ndarray:
+        """Concatenate per-rank numpy blocks along ``axis`` (end-of-run history collection)."""
+        objs = [None] * self.world
+        self.dist.all_gather_object(objs, local, group=self.group)
+        return np.concatenate(objs, axis=axis)

@@ -1,0 +1,218 @@
+/*
+ * gdpso.h -- C ABI of libgdpso.so: the PSO latent-discovery hot path on MI355X (gfx950).
+ *
+ * The reference (ltronchin/Gan-discovery-PSO) is pure Python and has no FFI of its own;
+ * each entry point below replaces the Python function(s) named in its comment
+ * (paths relative to the reference root).  All signatures are plain C: pointers, sizes
+ * and scalars.  Unless a parameter is marked HOST, pointers are device pointers on the
+ * current HIP device; `stream` is a hipStream_t passed as void*.  Every call is
+ * asynchronous on `stream` and never synchronises, allocates or frees device memory,
+ * except the *_create / *_destroy functions (set-up time only).
+ *
+ * Return value: 0 on success, a GDPSO_ERR_* code otherwise; gdpso_last_error() gives the
+ * message of the calling thread's most recent failure.
+ *
+ * Layouts: activations are NHWC fp32; swarm state is float64 (positions, velocities,
+ * personal bests: the reference keeps them in numpy float64) with float32 fitness values
+ * (the reference's fitness is a float32 array).
+ */
+#ifndef GDPSO_H
+#define GDPSO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GDPSO_ABI_VERSION 1
+
+#define GDPSO_OK 0
+#define GDPSO_ERR_ARG 1       /* bad argument / unsupported shape */
+#define GDPSO_ERR_HIP 2       /* a HIP runtime call failed */
+#define GDPSO_ERR_WORKSPACE 3 /* caller's workspace is too small */
+
+/* fitness modes: reference src/pso/util_discovery.py:75-78 */
+#define GDPSO_MODE_IN_TRAINING 0  /* fitness = min(p + thr, 1) + eps        */
+#define GDPSO_MODE_OUT_TRAINING 1 /* fitness = (1 - min(p + thr, 1)) + eps  */
+
+int gdpso_abi_version(void);
+const char *gdpso_last_error(void);
+
+/* ------------------------------------------------------------------ generator
+ * Replaces Generator.forward, reference src/utils/util_dcgan.py:128-149 (identical copies
+ * src/inverter/utils_ae/util_inverter.py:119-140 and
+ * src/inverter/utils_vq_vae/util_model.py:57-78, the VQ-VAE decoder used as generator),
+ * followed by the per-image min/max rescale of src/utils/util_data.py:129-135 as called
+ * from Discovery.particles_to_img, src/pso/util_discovery.py:33-50.
+ */
+typedef struct gdpso_generator gdpso_generator;
+
+/* `tensors` (HOST): 14 fp32 arrays in state_dict order and PyTorch layout:
+ *   gen.0.0.weight [Z,2F,k,k]  gen.0.0.bias [2F]
+ *   gen.0.1.weight, .bias, .running_mean, .running_var [2F]
+ *   gen.1.0.weight [2F,F,4,4]  gen.1.0.bias [F]
+ *   gen.1.1.weight, .bias, .running_mean, .running_var [F]
+ *   gen.2.weight [F,1,4,4]     gen.2.bias [1]
+ * first_kernel k is 7 in the reference (28x28 images); output side = 4k. */
+int gdpso_generator_create(gdpso_generator **out, int z_dim, int features_g, int first_kernel,
+                           const float *const *tensors, int n_tensors);
+void gdpso_generator_destroy(gdpso_generator *g);
+int gdpso_generator_image_side(const gdpso_generator *g);
+size_t gdpso_generator_workspace_bytes(const gdpso_generator *g, int n);
+
+/* z: [n, z_dim] latents, float64 if z_is_f64 else float32 (the reference casts float64
+ * positions to float32 before the generator, util_discovery.py:41-43).
+ * img   [n, S, S]: generator output in [-1,1]           (may be NULL)
+ * img01 [n, S, S]: (img - min) / (max - min) per image
+ * target [n, S, S] + mse [n]: optional (both or neither); mse[i] = mean((target_i - img_i)^2),
+ * the reconstruction term of Discovery.fitness_pso_inverter, util_discovery.py:97. */
+int gdpso_generator_forward(const gdpso_generator *g, void *stream, int n, const void *z, int z_is_f64,
+                            float *img, float *img01, const float *target, float *mse,
+                            void *workspace, size_t workspace_bytes);
+
+/* ------------------------------------------------------------------- assessor
+ * Replaces Resnet.forward + resnet_block.forward, reference src/pso/util_cnn.py:81-190,
+ * built by get_cnn (:24-38), and the softmax/fitness tail of Discovery.fitness,
+ * src/pso/util_discovery.py:66-80 (+ :84-101 for the inverter variant).
+ */
+typedef struct gdpso_assessor gdpso_assessor;
+
+/* depths: blocks per stage ({3,4,6,3} = ResNet50, {3,4,23,3} = 101, {3,8,36,3} = 152).
+ * Only 1 input channel is supported (the reference's data.channel).
+ * `tensors` (HOST) fp32, PyTorch layout, in forward order:
+ *   conv1.weight [64,1,7,7], bn1.{weight,bias,running_mean,running_var}
+ *   then for every block: conv1.weight, bn1.x4, conv2.weight, bn2.x4, conv3.weight, bn3.x4,
+ *        and, on the first block of each stage, identity_downsample.0.weight,
+ *        identity_downsample.1.x4
+ *   fc.weight [n_class,2048], fc.bias [n_class]
+ * img_side: input image side the plan is specialised for (28, 64, ...). */
+int gdpso_assessor_create_resnet(gdpso_assessor **out, const int depths[4], int n_class, int img_side,
+                                 const float *const *tensors, int n_tensors);
+void gdpso_assessor_destroy(gdpso_assessor *a);
+size_t gdpso_assessor_workspace_bytes(const gdpso_assessor *a, int n);
+int gdpso_assessor_n_class(const gdpso_assessor *a);
+/* nominal dense FLOPs of one image (2 per multiply-accumulate, padding taps included) */
+double gdpso_assessor_flops_per_image(const gdpso_assessor *a);
+
+/* img01 [n, S, S] -> logits [n, n_class] (may be NULL) and/or fitness [n] (may be NULL).
+ * fitness = mode(p[class_index], threshold) + eps, p = softmax(logits); with two classes
+ * index 1 is used whatever class_index says (util_discovery.py:71-74).
+ * mse (may be NULL): when given, fitness = w_ass*fitness + w_rec*mse + eps
+ * (util_discovery.py:86-101: eps is added a second time). */
+int gdpso_assessor_forward(const gdpso_assessor *a, void *stream, int n, const float *img01,
+                           float *logits, float *fitness, int class_index, int mode, float threshold,
+                           float eps, const float *mse, float w_ass, float w_rec,
+                           void *workspace, size_t workspace_bytes);
+
+/* --------------------------------------------------------------------- encoder
+ * Replaces Encoder.forward, reference src/inverter/utils_ae/util_inverter.py:164-184
+ * (used once to seed particle positions, src/pso/util_pso.py:93-112).
+ * `tensors` (HOST): enc.0.weight [F,1,4,4], enc.0.bias, enc.2.0.weight [2F,F,4,4],
+ * enc.2.0.bias, enc.3.weight [Z,2F,7,7], enc.3.bias. */
+typedef struct gdpso_encoder gdpso_encoder;
+int gdpso_encoder_create(gdpso_encoder **out, int enc_dim, int features_e, const float *const *tensors,
+                         int n_tensors);
+void gdpso_encoder_destroy(gdpso_encoder *e);
+size_t gdpso_encoder_workspace_bytes(const gdpso_encoder *e, int n);
+/* img [n,28,28] in [-1,1] -> latent [n, enc_dim] fp32 */
+int gdpso_encoder_forward(const gdpso_encoder *e, void *stream, int n, const float *img, float *latent,
+                          void *workspace, size_t workspace_bytes);
+
+/* ----------------------------------------------------------------------- swarm
+ * Replaces Particle / Swarm arithmetic, reference src/pso/util_pso.py:24-193.
+ * All buffers are caller-owned device memory.
+ */
+typedef struct {
+    int n;              /* particles held by this process                      */
+    int d;              /* dim_space                                           */
+    int first_index;    /* global index of local particle 0 (0 on one GPU)     */
+    int n_ranks;        /* processes sharing the swarm (1 on one GPU)          */
+    double *pos;        /* [n,d]                                               */
+    double *vel;        /* [n,d]                                               */
+    double *pbest_pos;  /* [n,d]                                               */
+    float *pbest_val;   /* [n]   +inf before the first evaluation              */
+    float *fitness;     /* [n]   written by the assessor                       */
+    double *gbest_pos;  /* [d]                                                 */
+    /* control block, >= GDPSO_CTRL_DOUBLES doubles, zero-filled then initialised by
+     * gdpso_swarm_reset: [0] w_inertia  [1] gbest_val  [2] gbest global index
+     * [3] number of entries in g_best_val  [4] stop iteration (0 = running)
+     * [5] iterations completed */
+    double *ctrl;
+    float *g_best_val;        /* [max_iter+1] grows on improvement only (util_pso.py:143-149) */
+    float *g_best_val_dummy;  /* [max_iter]   one entry per iteration (util_pso.py:151)       */
+    double *mean_dist;        /* [max_iter]   mean pairwise distance (util_pso.py:76-86), may be NULL */
+    double *hist_pos;         /* [max_iter+1, n, d] particle.history, may be NULL     */
+    double *hist_vel;         /* [max_iter+1, n, d] particle.history_vel, may be NULL */
+    double *cand;             /* [n_ranks, d+2] candidate records {val, global idx, pos[d]} */
+    void *scratch;            /* >= gdpso_swarm_scratch_bytes(n), n = the largest particle count
+                                 passed to local_best / mean_distance */
+    size_t scratch_bytes;
+    int max_iter;
+} gdpso_swarm;
+
+#define GDPSO_CTRL_DOUBLES 8
+#define GDPSO_CTRL_W 0
+#define GDPSO_CTRL_GBEST_VAL 1
+#define GDPSO_CTRL_GBEST_IDX 2
+#define GDPSO_CTRL_N_IMPROVE 3
+#define GDPSO_CTRL_STOP_ITER 4
+#define GDPSO_CTRL_ITERS_DONE 5
+
+size_t gdpso_swarm_scratch_bytes(int n);
+
+/* Swarm.__init__ + the bookkeeping of Particle.__init__ (util_pso.py:25-37, 54-70):
+ * pbest_pos = pos, pbest_val = +inf, g_best_val = [inf], history[0] = pos / vel.
+ * pos and vel must already hold the initial state. */
+int gdpso_swarm_reset(const gdpso_swarm *s, void *stream, double w_inertia);
+
+/* Swarm.update_personal_best compare-and-copy (util_pso.py:122-124) for the local
+ * particles, then this rank's best candidate -> s->cand[rank_slot]. */
+int gdpso_swarm_local_best(const gdpso_swarm *s, void *stream, int iteration, int rank_slot);
+
+/* Swarm.update_global_best (util_pso.py:135-151) over the n_ranks candidate records in
+ * s->cand (after the all-gather when n_ranks > 1), the inertia decay of :178-179 and the
+ * early-stopping test of :186-188. */
+int gdpso_swarm_global_best(const gdpso_swarm *s, void *stream, int iteration, int schedule_inertia,
+                            int early_stopping, double tolerance);
+
+/* Swarm.move_particles (util_pso.py:153-157; Particle.update_velocity :43-50 and
+ * update_position :39-41).  rand [n,2] float64 = (r1, r2) per particle, or NULL to draw
+ * them on the device from Philox4x32-10 keyed by (seed, global particle index, iteration). */
+int gdpso_swarm_move(const gdpso_swarm *s, void *stream, int iteration, double w_cogn, double w_soci,
+                     const double *rand, uint64_t seed);
+
+/* Swarm.mse (util_pso.py:76-86): mean Euclidean distance over all unordered pairs of
+ * `pos_all` [n_all, d] -> s->mean_dist[iteration-1]. */
+int gdpso_swarm_mean_distance(const gdpso_swarm *s, void *stream, int iteration, const double *pos_all,
+                              int n_all);
+
+/* One whole iteration on one GPU (n_ranks == 1): generator, rescale, assessor, fitness,
+ * personal/global best, move, optional diagnostics -- the body of the while loop in
+ * Swarm.optimize, util_pso.py:174-189.  `target` switches on the inverter variant. */
+typedef struct {
+    int class_index, mode;
+    float threshold, eps;
+    const float *target;  /* [n,S,S] or NULL */
+    float w_ass, w_rec;
+    double w_cogn, w_soci;
+    int schedule_inertia, early_stopping;
+    double tolerance;
+    const double *rand;   /* [max_iter, n, 2] or NULL (device RNG) */
+    uint64_t seed;
+    int diagnostics;      /* compute mean pairwise distance each iteration */
+    float *img01;         /* [n,S,S] scratch for the rescaled images */
+    float *img;           /* [n,S,S] scratch for the raw images      */
+    float *mse;           /* [n] scratch (inverter variant)          */
+    void *workspace;      /* >= max(generator, assessor workspace)   */
+    size_t workspace_bytes;
+} gdpso_run;
+
+int gdpso_swarm_iterate(const gdpso_swarm *s, const gdpso_generator *g, const gdpso_assessor *a,
+                        const gdpso_run *r, void *stream, int first_iteration, int n_iterations);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GDPSO_H */
