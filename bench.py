@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Benchmark of the PSO latent-discovery hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--particles P]
+
+One step = one swarm iteration over P particles per GPU (default 512, the
+"DCGAN-MNIST 28x28, 512 particles, 1xMI355X, fp32" configuration): generator forward,
+per-image rescale, ResNet50 assessor forward, fitness, personal/global best, move, and
+the mean-pairwise-distance diagnostic and history appends the reference's loop also does
+every iteration (src/pso/util_pso.py:174-189).  Weights are synthetic (random-init),
+latents start N(0,1), r1/r2 come from the device RNG.  Swarm state, weights and
+workspaces are resident in HBM before the timed region; nothing crosses PCIe inside it.
+
+With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank holds P
+particles of one N*P-particle swarm (weak scaling) and the ranks exchange one
+{value, index, position} record per iteration over RCCL.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X dense fp32-input MFMA (= fp32 vector peak)
+
+
+def cpu_baseline(z_dim, n_class, class_index, seconds_budget=20.0):
+    """The oracle's restatement of the reference loop (one particle per forward pass,
+    pairwise-distance diagnostic on, no plotting), timed on this box's host cores on a
+    bounded sample: 64 particles, as many iterations as fit the budget (at least 1)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pso_oracle as oracle
+    synth = importlib.import_module("gan-discovery-pso_amd.synth")
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    gsd = synth.to_torch(synth.generator_state(z_dim, 1, 64, seed=11))
+    csd = synth.to_torch(synth.resnet_state("ResNet50", 1, n_class, seed=12))
+    fit = oracle.Fitness(gsd, csd, class_index)
+    rs = np.random.RandomState(42)
+    n = 64
+    pos, vel = oracle.init_swarm(n, z_dim, rs)
+    fit(pos[:2])  # first-touch of the torch CPU kernels is not what is being measured
+    t0 = time.perf_counter()
+    oracle.run_swarm(fit, pos, vel, 1, 0.73, 1.496, 1.496, early_stopping=False, rng=rs, batch=1, record=False)
+    one = time.perf_counter() - t0
+    iters = int(max(1, min(8, seconds_budget // max(one, 1e-3))))
+    t0 = time.perf_counter()
+    oracle.run_swarm(fit, pos, vel, iters, 0.73, 1.496, 1.496, early_stopping=False, rng=rs, batch=1, record=False)
+    dt = time.perf_counter() - t0
+    return {"value": round(n * iters / dt, 2), "unit": "particle-evals/s", "cores": threads, "kind": "port",
+            "sample": f"{n} particles x {iters} iterations, one particle per forward pass (reference-style loop), torch CPU fp32"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--particles", type=int, default=512, help="particles per GPU")
+    ap.add_argument("--z-dim", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    comm = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    eng = importlib.import_module("gan-discovery-pso_amd.engine")
+    synth = importlib.import_module("gan-discovery-pso_amd.synth")
+    lib = importlib.import_module("gan-discovery-pso_amd._lib")
+    if world > 1:
+        comm = eng.TorchComm()
+
+    z_dim, n_class, class_index = args.z_dim, 8, 6
+    gen = eng.PackedGenerator(synth.generator_state(z_dim, 1, 64, seed=11), dev)
+    ass = eng.PackedAssessor(synth.resnet_state("ResNet50", 1, n_class, seed=12), dev, img_side=gen.side)
+    ev = eng.Evaluator(gen, ass)
+    spec = eng.FitnessSpec(class_index=class_index)
+    p, k, w = args.particles, args.steps, args.warmup
+    n_global = p * world
+    lo = rank * p
+    sw = eng.HipSwarm(ev, p, z_dim, 2 * (w + k), first_index=lo, n_ranks=world, rank=rank, n_global=n_global,
+                      history=True, diagnostics=True)
+    rs = np.random.RandomState(42)
+    r = rs.standard_normal((n_global, 2, z_dim))
+    sw.load(r[lo:lo + p, 0], (r[lo:lo + p, 1] - 0.5) / 10, 0.73)
+
+    def run(first, count):
+        if comm is None:
+            sw.iterate(first, count, spec, 1.496, 1.496, False, False, 1e-5, True, seed=42)
+        else:
+            for i in range(first, first + count):
+                sw.evaluate(i, spec)
+                sw.local_best(i)
+                comm.all_gather(sw.cand, sw.cand[sw.rank])
+                sw.global_best(i, False, False, 1e-5)
+                sw.move(i, 1.496, 1.496, seed=42)
+                sw.mean_distance(i, comm.gather_positions(sw.pos, n_global))
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if comm is not None:
+            comm.dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    run(1, w)
+    fence()
+    t0 = time.perf_counter()
+    run(w + 1, k)
+    fence()
+    dt = time.perf_counter() - t0
+    if comm is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        comm.dist.all_reduce(t, op=comm.dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ctrl = sw.control()
+    assert int(ctrl[lib.CTRL_ITERS_DONE]) == w + k, "the loop did not run every iteration"
+
+    # second pass of K steps with HIP events around every convolution launch (same stream)
+    roofline = None
+    if rank == 0:
+        L = lib.lib()
+        lib.check(L.gdpso_conv_timing_begin(64 * k))
+        if comm is None:
+            run(w + k + 1, k)
+            torch.cuda.synchronize(dev)
+        else:  # price the kernel on this rank's own shard without the other ranks
+            for i in range(w + k + 1, w + 2 * k + 1):
+                sw.evaluate(i, spec)
+            torch.cuda.synchronize(dev)
+        ms, launches, flops = C.c_double(), C.c_int(), C.c_double()
+        lib.check(L.gdpso_conv_timing_end(C.byref(ms), C.byref(launches), C.byref(flops)))
+        achieved = flops.value / (ms.value * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "conv_gemm_kernel (fp32-input MFMA implicit GEMM)",
+                    "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": launches.value // k, "avg_launch_us": round(1e3 * ms.value / launches.value, 3),
+                    "conv_ms_per_step": round(ms.value / k, 4),
+                    "algorithmic_gflop_per_step": round(flops.value / k / 1e9, 3)}
+    if comm is not None:
+        comm.dist.barrier()
+
+    if rank == 0:
+        value = n_global * k / dt
+        flop_per_eval = gen.flops_per_image + ass.flops_per_image
+        out = {
+            "metric": "particle-evaluations/sec (swarm x gen-fwd) DCGAN-MNIST", "value": round(value, 1),
+            "unit": "particle-evals/s", "n_gpus": world, "steps": k, "warmup": w, "ms_per_step": round(1e3 * dt / k, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"DCGAN-MNIST 28x28, {p} particles per GPU, ResNet50 assessor (n_class=8), z_dim={z_dim}, "
+                                   f"{n_global} particles total", "particles_per_gpu": p, "z_dim": z_dim,
+                       "flop_per_particle_eval": flop_per_eval, "parallelism": f"particle shards x{world}"},
+            "end_to_end_tflops": round(value * flop_per_eval / 1e12, 3),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(z_dim, n_class, class_index)
+        print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -42,7 +42,7 @@ class RunDesc(C.Structure):
         ("target", c_void_p), ("w_ass", c_float), ("w_rec", c_float),
         ("w_cogn", c_double), ("w_soci", c_double),
         ("schedule_inertia", c_int), ("early_stopping", c_int), ("tolerance", c_double),
-        ("rand", c_void_p), ("seed", c_uint64), ("diagnostics", c_int),
+        ("rand", c_void_p), ("seed", c_uint64), ("diagnostics", c_int), ("f32_first_move", c_int),
         ("img01", c_void_p), ("img", c_void_p), ("mse", c_void_p),
         ("workspace", c_void_p), ("workspace_bytes", c_size_t),
     ]
@@ -72,8 +72,10 @@ _PROTOTYPES = {
     "gdpso_swarm_reset": (c_int, [C.POINTER(SwarmDesc), c_void_p, c_double]),
     "gdpso_swarm_local_best": (c_int, [C.POINTER(SwarmDesc), c_void_p, c_int, c_int]),
     "gdpso_swarm_global_best": (c_int, [C.POINTER(SwarmDesc), c_void_p, c_int, c_int, c_int, c_double]),
-    "gdpso_swarm_move": (c_int, [C.POINTER(SwarmDesc), c_void_p, c_int, c_double, c_double, c_void_p, c_uint64]),
+    "gdpso_swarm_move": (c_int, [C.POINTER(SwarmDesc), c_void_p, c_int, c_double, c_double, c_void_p, c_uint64, c_int]),
     "gdpso_swarm_mean_distance": (c_int, [C.POINTER(SwarmDesc), c_void_p, c_int, c_void_p, c_int]),
+    "gdpso_conv_timing_begin": (c_int, [c_int]),
+    "gdpso_conv_timing_end": (c_int, [C.POINTER(c_double), C.POINTER(c_int), C.POINTER(c_double)]),
     "gdpso_swarm_iterate": (c_int, [C.POINTER(SwarmDesc), c_void_p, c_void_p, C.POINTER(RunDesc), c_void_p, c_int, c_int]),
 }
 

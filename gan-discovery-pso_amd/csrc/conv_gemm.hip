@@ -219,6 +219,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
 }
 
 // --------------------------------------------------------------------------- host side
+// Optional per-launch timing of the convolution kernel with HIP events recorded on the
+// launch stream (used by the benchmark to price the kernel against its roofline).
+namespace {
+struct ConvTiming {
+    bool on = false;
+    std::vector<hipEvent_t> events;
+    size_t used = 0;
+    double flops = 0.0;
+} g_timing;
+}  // namespace
+
 static long max_ktot(const ConvLayer &L) {
     long k = 0;
     for (int p = 0; p < L.nphase; ++p) k = std::max<long>(k, (long)L.phase[p].ntaps * L.cin);
@@ -271,10 +282,17 @@ int launch_conv(const ConvLayer &L, hipStream_t stream, int n_images, const floa
     if (L.splits > 1 && !splitk_ws) return fail(GDPSO_ERR_WORKSPACE, "conv: split-K workspace missing");
     const int tiles_m = ceil_div(a.M, L.tile);
     dim3 grid(tiles_m * a.tiles_n, 1, L.nphase * L.splits);
+    const bool timed = g_timing.on && g_timing.used + 2 <= g_timing.events.size();
+    if (timed) GDPSO_HIP(hipEventRecord(g_timing.events[g_timing.used], stream));
     if (L.tile == 128)
         hipLaunchKernelGGL((conv_gemm_kernel<128, 128>), grid, dim3(256), 0, stream, a);
     else
         hipLaunchKernelGGL((conv_gemm_kernel<64, 64>), grid, dim3(256), 0, stream, a);
+    if (timed) {
+        GDPSO_HIP(hipEventRecord(g_timing.events[g_timing.used + 1], stream));
+        g_timing.used += 2;
+        g_timing.flops += L.flops_nominal * n_images;
+    }
     if (L.splits > 1) {
         const long quads = a.slab / 4;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ceil_div(quads, 256)), dim3(256), 0, stream, a.part, L.splits,
@@ -285,3 +303,33 @@ int launch_conv(const ConvLayer &L, hipStream_t stream, int n_images, const floa
 }
 
 }  // namespace gdpso
+
+extern "C" int gdpso_conv_timing_begin(int max_launches) {
+    using namespace gdpso;
+    GDPSO_REQUIRE(max_launches > 0, "conv_timing_begin: max_launches must be positive");
+    while (g_timing.events.size() < (size_t)2 * max_launches) {
+        hipEvent_t e;
+        GDPSO_HIP(hipEventCreate(&e));
+        g_timing.events.push_back(e);
+    }
+    g_timing.used = 0;
+    g_timing.flops = 0.0;
+    g_timing.on = true;
+    return GDPSO_OK;
+}
+
+extern "C" int gdpso_conv_timing_end(double *total_ms, int *launches, double *flops) {
+    using namespace gdpso;
+    g_timing.on = false;
+    double ms = 0.0;
+    for (size_t i = 0; i + 1 < g_timing.used; i += 2) {
+        GDPSO_HIP(hipEventSynchronize(g_timing.events[i + 1]));
+        float t = 0.f;
+        GDPSO_HIP(hipEventElapsedTime(&t, g_timing.events[i], g_timing.events[i + 1]));
+        ms += t;
+    }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = (int)(g_timing.used / 2);
+    if (flops) *flops = g_timing.flops;
+    return GDPSO_OK;
+}

@@ -202,7 +202,7 @@ __device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {
 //   vel = (inertia + best_soci) + best_cogn ;  pos = pos + vel
 // r1, r2 are scalars per particle.  One thread per (particle, dimension) element.
 __global__ __launch_bounds__(256) void move_kernel(gdpso_swarm s, int iteration, double w_cogn, double w_soci,
-                                                   const double *__restrict__ rnd, uint64_t seed) {
+                                                   const double *__restrict__ rnd, uint64_t seed, int f32_terms) {
     if (!running(s.ctrl, iteration)) return;
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= (long)s.n * s.d) return;
@@ -221,9 +221,18 @@ __global__ __launch_bounds__(256) void move_kernel(gdpso_swarm s, int iteration,
     const double x = s.pos[e], v = s.vel[e];
     const double inertia = w * v;
     const double c1 = w_cogn * r1;
-    const double best_cogn = c1 * (s.gbest_pos[k] - x);
     const double c2 = w_soci * r2;
-    const double best_soci = c2 * (s.pbest_pos[e] - x);
+    double best_cogn, best_soci;
+    if (f32_terms) {
+        // float32 positions (first move of the inverter variant): numpy keeps float32 for
+        // array - array and for python-float * float32-array
+        const float xf = (float)x;
+        best_cogn = (double)((float)c1 * ((float)s.gbest_pos[k] - xf));
+        best_soci = (double)((float)c2 * ((float)s.pbest_pos[e] - xf));
+    } else {
+        best_cogn = c1 * (s.gbest_pos[k] - x);
+        best_soci = c2 * (s.pbest_pos[e] - x);
+    }
     const double nv = (inertia + best_soci) + best_cogn;
     const double nx = x + nv;
     s.vel[e] = nv;
@@ -236,8 +245,14 @@ __global__ __launch_bounds__(256) void move_kernel(gdpso_swarm s, int iteration,
 // Swarm.mse (util_pso.py:76-86): mean Euclidean distance over unordered pairs.  Tile of
 // 64 x 64 pairs per workgroup (upper triangle only), float64 throughout; per-workgroup sums
 // are combined in a fixed order by the finishing kernel, so the result is reproducible.
-constexpr int DT = 64;
-__global__ __launch_bounds__(256) void pair_dist_kernel(const double *__restrict__ pos, int n, int d, int tiles,
+// DT particles per tile side: the largest power of two in [8, 64] whose two tiles fit 48 KiB.
+constexpr int DT_MIN = 8;
+static int dist_tile_side(int d) {
+    int dt = 64;
+    while (dt > DT_MIN && (size_t)2 * dt * d * sizeof(double) > 48 * 1024) dt >>= 1;
+    return dt;
+}
+__global__ __launch_bounds__(256) void pair_dist_kernel(const double *__restrict__ pos, int n, int d, int DT, int tiles,
                                                         const double *ctrl, int iteration, double *__restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) double sd[];  // [2][DT][d]
     __shared__ double s_sum[4];
@@ -300,8 +315,8 @@ static int check_swarm(const gdpso_swarm *s) {
     return GDPSO_OK;
 }
 
-static size_t dist_tiles(int n) {
-    const size_t t = (size_t)ceil_div(n, DT);
+static size_t dist_tiles(int n, int dt) {
+    const size_t t = (size_t)ceil_div(n, dt);
     return t * (t + 1) / 2;
 }
 
@@ -312,7 +327,8 @@ using namespace gdpso;
 extern "C" size_t gdpso_swarm_scratch_bytes(int n) {
     if (n <= 0) return 0;
     const size_t partials = (size_t)ceil_div(n, PB) * sizeof(BestRec);
-    return (partials + 255) / 256 * 256 + dist_tiles(n) * sizeof(double) + 256;
+    // distance partials sized for the smallest tile side, whatever dim_space turns out to be
+    return (partials + 255) / 256 * 256 + dist_tiles(n, DT_MIN) * sizeof(double) + 256;
 }
 
 extern "C" int gdpso_swarm_reset(const gdpso_swarm *s, void *stream, double w_inertia) {
@@ -350,13 +366,13 @@ extern "C" int gdpso_swarm_global_best(const gdpso_swarm *s, void *stream, int i
 }
 
 extern "C" int gdpso_swarm_move(const gdpso_swarm *s, void *stream, int iteration, double w_cogn, double w_soci,
-                                const double *rnd, uint64_t seed) {
+                                const double *rnd, uint64_t seed, int f32_first_move) {
     int rc = check_swarm(s);
     if (rc) return rc;
     GDPSO_REQUIRE(iteration >= 1 && iteration <= s->max_iter, "swarm_move: iteration out of range");
     const long nd = (long)s->n * s->d;
     hipLaunchKernelGGL(move_kernel, dim3(ceil_div(nd, 256)), dim3(256), 0, (hipStream_t)stream, *s, iteration, w_cogn, w_soci,
-                       rnd, seed);
+                       rnd, seed, (f32_first_move && iteration == 1) ? 1 : 0);
     GDPSO_HIP(hipGetLastError());
     return GDPSO_OK;
 }
@@ -367,13 +383,14 @@ extern "C" int gdpso_swarm_mean_distance(const gdpso_swarm *s, void *stream, int
     GDPSO_REQUIRE(s->mean_dist && pos_all, "swarm_mean_distance: null buffer");
     GDPSO_REQUIRE(iteration >= 1 && iteration <= s->max_iter, "swarm_mean_distance: iteration out of range");
     GDPSO_REQUIRE(n_all >= 2, "swarm_mean_distance: needs at least two particles");
+    const int DT = dist_tile_side(s->d);
     GDPSO_REQUIRE((size_t)2 * DT * s->d * sizeof(double) <= 64 * 1024, "swarm_mean_distance: dim_space too large");
     GDPSO_REQUIRE(gdpso_swarm_scratch_bytes(std::max(n_all, s->n)) <= s->scratch_bytes, "swarm_mean_distance: scratch too small");
     const int tiles = ceil_div(n_all, DT);
-    const int nb = (int)dist_tiles(n_all);
+    const int nb = (int)dist_tiles(n_all, DT);
     double *partial = (double *)((char *)s->scratch + ((size_t)ceil_div(s->n, PB) * sizeof(BestRec) + 255) / 256 * 256);
     hipLaunchKernelGGL(pair_dist_kernel, dim3(nb), dim3(256), (size_t)2 * DT * s->d * sizeof(double), (hipStream_t)stream, pos_all,
-                       n_all, s->d, tiles, s->ctrl, iteration, partial);
+                       n_all, s->d, DT, tiles, s->ctrl, iteration, partial);
     hipLaunchKernelGGL(pair_dist_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, nb, n_all, s->ctrl, iteration,
                        s->mean_dist);
     GDPSO_HIP(hipGetLastError());
@@ -401,7 +418,7 @@ extern "C" int gdpso_swarm_iterate(const gdpso_swarm *s, const gdpso_generator *
         if ((rc = gdpso_swarm_local_best(s, stream, i, 0))) return rc;
         if ((rc = gdpso_swarm_global_best(s, stream, i, r->schedule_inertia, r->early_stopping, r->tolerance))) return rc;
         const double *rnd = r->rand ? r->rand + (size_t)(i - 1) * s->n * 2 : nullptr;
-        if ((rc = gdpso_swarm_move(s, stream, i, r->w_cogn, r->w_soci, rnd, r->seed))) return rc;
+        if ((rc = gdpso_swarm_move(s, stream, i, r->w_cogn, r->w_soci, rnd, r->seed, r->f32_first_move))) return rc;
         if (r->diagnostics && s->mean_dist && s->n >= 2)
             if ((rc = gdpso_swarm_mean_distance(s, stream, i, s->pos, s->n))) return rc;
     }

@@ -245,7 +245,7 @@ class HipSwarm:
     and the per-phase kernel launches.  One instance per process / GPU."""
 
     def __init__(self, evaluator: Evaluator, n_local, d, max_iter, *, first_index=0, n_ranks=1, rank=0, n_global=None,
-                 history=True, diagnostics=True):
+                 history=True, diagnostics=True, record_fitness=False):
         self.ev, self.device = evaluator, evaluator.device
         self.n, self.d, self.max_iter = int(n_local), int(d), int(max_iter)
         self.first_index, self.n_ranks, self.rank = int(first_index), int(n_ranks), int(rank)
@@ -269,9 +269,10 @@ class HipSwarm:
         self.cand = torch.zeros(self.n_ranks, d + 2, dtype=f64, device=dev)
         nscr = max(self.n_global, n) if diagnostics else n
         self.scratch = torch.zeros(_lib.lib().gdpso_swarm_scratch_bytes(nscr), dtype=torch.uint8, device=dev)
-        self.fit_hist = torch.zeros(t, n, dtype=f32, device=dev) if history else None
+        self.fit_hist = torch.zeros(t, n, dtype=f32, device=dev) if record_fitness else None
         self.rand = None
         self.target = None
+        self.f32_first_move = False
         self.desc = _lib.SwarmDesc(
             n=n, d=d, first_index=self.first_index, n_ranks=self.n_ranks, pos=ptr(self.pos), vel=ptr(self.vel),
             pbest_pos=ptr(self.pbest_pos), pbest_val=ptr(self.pbest_val), fitness=ptr(self.fitness),
@@ -318,7 +319,8 @@ class HipSwarm:
     def move(self, i, w_cogn, w_soci, seed=0):
         rnd = 0 if self.rand is None else self.rand[i - 1].data_ptr()
         with torch.cuda.device(self.device):
-            check(_lib.lib().gdpso_swarm_move(C.byref(self.desc), self._stream(), i, float(w_cogn), float(w_soci), rnd, int(seed)))
+            check(_lib.lib().gdpso_swarm_move(C.byref(self.desc), self._stream(), i, float(w_cogn), float(w_soci), rnd, int(seed),
+                                              int(self.f32_first_move)))
 
     def mean_distance(self, i, pos_all: torch.Tensor):
         with torch.cuda.device(self.device):
@@ -333,6 +335,7 @@ class HipSwarm:
                            target=ptr(self.target), w_ass=spec.w_ass, w_rec=spec.w_rec, w_cogn=w_cogn, w_soci=w_soci,
                            schedule_inertia=int(schedule_inertia), early_stopping=int(early_stopping), tolerance=tolerance,
                            rand=ptr(self.rand), seed=int(seed), diagnostics=int(bool(diagnostics) and self.mean_dist is not None),
+                           f32_first_move=int(self.f32_first_move),
                            img01=ptr(img01), img=ptr(img), mse=ptr(mse), workspace=ptr(ws), workspace_bytes=ws.numel())
         with torch.cuda.device(self.device):
             if self.fit_hist is None:
@@ -365,6 +368,7 @@ class HipSwarm:
         if self.hist_pos is not None:
             out["hist_pos"] = self.hist_pos[:iters + 1].cpu().numpy()
             out["hist_vel"] = self.hist_vel[:iters + 1].cpu().numpy()
+        if self.fit_hist is not None:
             out["fitness"] = self.fit_hist[:iters].cpu().numpy()
         return out
 

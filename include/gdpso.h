@@ -179,9 +179,12 @@ int gdpso_swarm_global_best(const gdpso_swarm *s, void *stream, int iteration, i
 
 /* Swarm.move_particles (util_pso.py:153-157; Particle.update_velocity :43-50 and
  * update_position :39-41).  rand [n,2] float64 = (r1, r2) per particle, or NULL to draw
- * them on the device from Philox4x32-10 keyed by (seed, global particle index, iteration). */
+ * them on the device from Philox4x32-10 keyed by (seed, global particle index, iteration).
+ * f32_first_move: in the inverter variant the initial positions are float32 encoder outputs
+ * (util_pso.py:106-110), so numpy evaluates the two attraction terms of iteration 1 in
+ * float32; set it to reproduce that rounding (only iteration 1 is affected). */
 int gdpso_swarm_move(const gdpso_swarm *s, void *stream, int iteration, double w_cogn, double w_soci,
-                     const double *rand, uint64_t seed);
+                     const double *rand, uint64_t seed, int f32_first_move);
 
 /* Swarm.mse (util_pso.py:76-86): mean Euclidean distance over all unordered pairs of
  * `pos_all` [n_all, d] -> s->mean_dist[iteration-1]. */
@@ -202,6 +205,7 @@ typedef struct {
     const double *rand;   /* [max_iter, n, 2] or NULL (device RNG) */
     uint64_t seed;
     int diagnostics;      /* compute mean pairwise distance each iteration */
+    int f32_first_move;   /* see gdpso_swarm_move */
     float *img01;         /* [n,S,S] scratch for the rescaled images */
     float *img;           /* [n,S,S] scratch for the raw images      */
     float *mse;           /* [n] scratch (inverter variant)          */
@@ -211,6 +215,15 @@ typedef struct {
 
 int gdpso_swarm_iterate(const gdpso_swarm *s, const gdpso_generator *g, const gdpso_assessor *a,
                         const gdpso_run *r, void *stream, int first_iteration, int n_iterations);
+
+/* -------------------------------------------------------------------- measurement
+ * No counterpart in the reference: a hook for benchmarks.  Between begin and end, every
+ * launch of the implicit-GEMM convolution kernel (generator, assessor and encoder
+ * convolutions) is bracketed by HIP events on its own stream; end() waits for them and
+ * returns the summed kernel time, the number of launches and their nominal FLOPs
+ * (2 per multiply-accumulate, padding taps included).  Not thread-safe. */
+int gdpso_conv_timing_begin(int max_launches);
+int gdpso_conv_timing_end(double *total_ms, int *launches, double *flops);
 
 #ifdef __cplusplus
 }
