@@ -22,6 +22,7 @@
 namespace gdpso {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int BK = 32;
 constexpr int LDA = BK + 4;  // 144-byte rows: ds_read_b128 of 16 consecutive rows is conflict-free
@@ -45,6 +46,12 @@ struct ConvKArgs {
     long slab;  // elements per split-K slab
 };
 
+// Taps that fall into the padding (and tail rows past M) read from here instead of
+// branching around the load: a conditional load would make the compiler wait for the whole
+// prefetch at the branch join, i.e. before the MFMAs it is supposed to overlap with.
+constexpr int MAX_CIN = 4096;
+__device__ __attribute__((aligned(128))) float g_zero_page[MAX_CIN + 32] = {};
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == ACT_RELU) return v > 0.f ? v : 0.f;
     if (act == ACT_LEAKY02) return v > 0.f ? v : 0.2f * v;
@@ -63,7 +70,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKArgs a) {
     const int wr = wave >> 1, wc = wave & 1;
     const int l31 = lane & 31, half = lane >> 5;
 
-    const int tm = blockIdx.x / a.tiles_n, tn = blockIdx.x - tm * a.tiles_n;
+    // Workgroups b and b+8 share an XCD (and its L2): give each XCD a contiguous run of
+    // tiles, so tiles that share input rows or weight columns hit the same L2.
+    const int nt = gridDim.x, xq = nt >> 3, xr = nt & 7;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + slot;
+    const int tm = tile / a.tiles_n, tn = tile - tm * a.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int ph = blockIdx.z / a.splits, sp = blockIdx.z - ph * a.splits;
     const int *tab = a.table + ph * PHASE_TABLE_INTS;
@@ -89,31 +101,55 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKArgs a) {
         a_ix0[p] = mx * a.in_stride;
         a_img[p] = n * a.hin * a.win;
     }
-    const float *wrow[PB];
-#pragma unroll
-    for (int p = 0; p < PB; ++p) wrow[p] = wt + (size_t)(n0 + lrow + 32 * p) * ktot + lcol;
-
-    float4 ra[PA], rb[PB];
-    auto gload = [&](int kt) {
-        const int tap = kt / a.cin, ci0 = kt - tap * a.cin;
-        const int packed = tab[4 + tap];
-        const int dy = (int)(short)(packed & 0xffff), dx = packed >> 16;
-#pragma unroll
-        for (int p = 0; p < PA; ++p) {
-            const int iy = a_iy0[p] + dy, ix = a_ix0[p] + dx;
-            const bool ok = a_ok[p] && (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
-            ra[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) ra[p] = *(const float4 *)(a.in + (size_t)(a_img[p] + iy * a.win + ix) * a.cin + ci0 + lcol);
-        }
-#pragma unroll
-        for (int p = 0; p < PB; ++p) rb[p] = *(const float4 *)(wrow[p] + kt);
-    };
-    auto sstore = [&](int buf) {
-#pragma unroll
-        for (int p = 0; p < PA; ++p) *(float4 *)&sA[buf * BM * LDA + (lrow + 32 * p) * LDA + lcol] = ra[p];
-#pragma unroll
-        for (int p = 0; p < PB; ++p) *(float4 *)&sB[buf * BN * LDA + (lrow + 32 * p) * LDA + lcol] = rb[p];
-    };
+    // Gather pointers advance by one K-tile (32 channels) per load and are recomputed only
+    // when the K range crosses into the next tap.  Rows whose tap falls in the padding (and
+    // tail rows past M) point into the zero page and advance like the others.
+    const float *aptr[PA], *bptr[PB];
+    int tap = kbeg / a.cin, ci0 = kbeg - tap * a.cin;
+#define GDPSO_SET_TAP(CI)                                                                                       \
+    {                                                                                                           \
+        const int packed_ = tab[4 + tap];                                                                       \
+        const int dy_ = (int)(short)(packed_ & 0xffff), dx_ = packed_ >> 16;                                    \
+        _Pragma("unroll") for (int p = 0; p < PA; ++p) {                                                        \
+            const int iy = a_iy0[p] + dy_, ix = a_ix0[p] + dx_;                                                 \
+            const bool ok = a_ok[p] && (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;        \
+            aptr[p] = ok ? a.in + (size_t)(a_img[p] + iy * a.win + ix) * a.cin + (CI) + lcol                    \
+                         : g_zero_page + (CI) + lcol;                                                           \
+        }                                                                                                       \
+    }
+    // Prefetch registers for the next K-tile.  Native vector types over fully unrolled loops:
+    // with HIP's float4 struct these arrays were not promoted to registers (they went to
+    // scratch, which put a wait behind every prefetch).
+    f32x4 ra[PA], rb[PB];
+#define GDPSO_GLOAD()                                                                                           \
+    {                                                                                                           \
+        _Pragma("unroll") for (int p = 0; p < PA; ++p) {                                                        \
+            ra[p] = *(const f32x4 *)aptr[p];                                                                    \
+            aptr[p] += BK;                                                                                      \
+        }                                                                                                       \
+        _Pragma("unroll") for (int p = 0; p < PB; ++p) {                                                        \
+            rb[p] = *(const f32x4 *)bptr[p];                                                                    \
+            bptr[p] += BK;                                                                                      \
+        }                                                                                                       \
+        ci0 += BK;                                                                                              \
+        if (ci0 == a.cin) {                                                                                     \
+            ci0 = 0;                                                                                            \
+            if (++tap < ntaps) GDPSO_SET_TAP(0)                                                                 \
+        }                                                                                                       \
+    }
+#define GDPSO_SSTORE(BUF)                                                                                       \
+    {                                                                                                           \
+        _Pragma("unroll") for (int p = 0; p < PA; ++p)                                                          \
+            *(f32x4 *)&sA[(BUF) * BM * LDA + (lrow + 32 * p) * LDA + lcol] = ra[p];                             \
+        _Pragma("unroll") for (int p = 0; p < PB; ++p)                                                          \
+            *(f32x4 *)&sB[(BUF) * BN * LDA + (lrow + 32 * p) * LDA + lcol] = rb[p];                             \
+    }
+    // Operand fragments of MFMA group G (8 k's) into register set SET.
+#define GDPSO_LOADFRAG(SET, G)                                                                                  \
+    {                                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < WM; ++i) av[SET][i] = *(const f32x4 *)(pa + i * 32 * LDA + (G) * 8); \
+        _Pragma("unroll") for (int j = 0; j < WN; ++j) bv[SET][j] = *(const f32x4 *)(pb + j * 32 * LDA + (G) * 8); \
+    }
 
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -124,73 +160,96 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     if (kbeg < kend) {
-        gload(kbeg);
-        sstore(0);
+        GDPSO_SET_TAP(ci0)
+#pragma unroll
+        for (int p = 0; p < PB; ++p) bptr[p] = wt + (size_t)(n0 + lrow + 32 * p) * ktot + kbeg + lcol;
+        GDPSO_GLOAD()
+        GDPSO_SSTORE(0)
     }
     __syncthreads();
     int buf = 0;
     for (int kt = kbeg; kt < kend; kt += BK) {
         const bool more = kt + BK < kend;
-        if (more) gload(kt + BK);
+        if (more) GDPSO_GLOAD()
         const float *pa = sA + buf * BM * LDA + (wr * (BM / 2) + l31) * LDA + half * 4;
         const float *pb = sB + buf * BN * LDA + (wc * (BN / 2) + l31) * LDA + half * 4;
         // Within a K-tile the 32 k's are consumed in a permuted order: MFMA step s of group g
         // takes k = 8g + 4*half + s from both operands, so each lane's four steps are one
-        // 16-byte LDS read.  The sum over k is the same set of products.
+        // 16-byte LDS read.  The sum over k is the same set of products.  The fragments of
+        // group g+1 are read while the MFMAs of group g issue.
+        f32x4 av[2][WM], bv[2][WN];
+        GDPSO_LOADFRAG(0, 0)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            float4 av[WM], bv[WN];
+            if (g < 3) GDPSO_LOADFRAG((g + 1) & 1, g + 1)
 #pragma unroll
-            for (int i = 0; i < WM; ++i) av[i] = *(const float4 *)(pa + i * 32 * LDA + g * 8);
-#pragma unroll
-            for (int j = 0; j < WN; ++j) bv[j] = *(const float4 *)(pb + j * 32 * LDA + g * 8);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
-                    for (int j = 0; j < WN; ++j) {
-                        const float x = s == 0 ? av[i].x : s == 1 ? av[i].y : s == 2 ? av[i].z : av[i].w;
-                        const float y = s == 0 ? bv[j].x : s == 1 ? bv[j].y : s == 2 ? bv[j].z : bv[j].w;
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc[i][j], 0, 0, 0);
-                    }
-            }
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1][i][s], bv[g & 1][j][s], acc[i][j], 0, 0, 0);
         }
-        if (more) sstore(buf ^ 1);
+        // pin the order: reads of group g+1 ahead of the MFMAs of group g (0x100 = DS read, 0x8 = MFMA)
+        __builtin_amdgcn_sched_group_barrier(0x100, WM + WN, 0);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x100, WM + WN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * WM * WN, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * WM * WN, 0);
+        if (more) GDPSO_SSTORE(buf ^ 1)
         __syncthreads();
         buf ^= 1;
     }
+#undef GDPSO_SET_TAP
+#undef GDPSO_GLOAD
+#undef GDPSO_SSTORE
+#undef GDPSO_LOADFRAG
 
-    // Epilogue.  Accumulator register r of lane l is C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]:
-    // the channel sits on the lane, so each store instruction writes two 128-byte row segments.
+    // Epilogue through LDS.  Accumulator register r of lane l is
+    // C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]; the tile is first laid out row-major
+    // in LDS (the K loop's last barrier has retired every operand read), then written with
+    // 16-byte stores: one wave instruction covers whole 256/512-byte row segments, and the
+    // residual is read the same way.
+    constexpr int LDC = BN + 4;
+    static_assert(BM * LDC <= 2 * (BM + BN) * LDA, "output tile must fit the operand buffers");
+    float *sC = lds;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                sC[(wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDC + wc * (BN / 2) + j * 32 + l31] = acc[i][j][r];
+    __syncthreads();
+    constexpr int C4 = BN / 4;     // float4 per tile row
+    constexpr int RPP = 256 / C4;  // tile rows per pass
+    const int c4 = tid % C4, r0 = tid / C4;
+    const int col = n0 + c4 * 4;
     const bool direct = a.splits == 1;
     float *dst = direct ? a.out : a.part + (size_t)sp * a.slab;
-#pragma unroll
-    for (int j = 0; j < WN; ++j) {
-        const int col = n0 + wc * (BN / 2) + j * 32 + l31;
-        const float sc = a.scale[col], sh = a.shift[col];
-#pragma unroll
-        for (int i = 0; i < WM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m >= a.M) continue;
-                size_t pix = (size_t)m;
-                if (a.out_mul != 1 || a.hm != a.hout || a.wm != a.wout) {
-                    const int n = m / hw, rr = m - n * hw;
-                    const int my = rr / a.wm, mx = rr - my * a.wm;
-                    pix = ((size_t)n * a.hout + my * a.out_mul + off_y) * a.wout + mx * a.out_mul + off_x;
-                }
-                const size_t o = pix * a.cout + col;
-                float v = acc[i][j][r];
-                if (direct) {
-                    v = v * sc + sh;
-                    if (a.res) v += a.res[o];
-                    v = apply_act(v, a.act);
-                }
-                dst[o] = v;
-            }
+    const f32x4 sc = *(const f32x4 *)(a.scale + col), sh = *(const f32x4 *)(a.shift + col);
+    const bool remap = a.out_mul != 1 || a.hm != a.hout || a.wm != a.wout;
+#pragma unroll 4
+    for (int pass = 0; pass < BM / RPP; ++pass) {
+        const int row = pass * RPP + r0, m = m0 + row;
+        if (m >= a.M) continue;
+        size_t pix = (size_t)m;
+        if (remap) {
+            const int n = m / hw, rr = m - n * hw;
+            const int my = rr / a.wm, mx = rr - my * a.wm;
+            pix = ((size_t)n * a.hout + my * a.out_mul + off_y) * a.wout + mx * a.out_mul + off_x;
         }
+        const size_t o = pix * a.cout + col;
+        f32x4 v = *(const f32x4 *)&sC[row * LDC + c4 * 4];
+        if (direct) {
+            v = v * sc + sh;
+            if (a.res) v += *(const f32x4 *)(a.res + o);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = apply_act(v[q], a.act);
+        }
+        *(f32x4 *)(dst + o) = v;
     }
 }
 
@@ -236,21 +295,22 @@ static long max_ktot(const ConvLayer &L) {
     return k;
 }
 
-// Chooses tile and split-K so that the launch fills the chip (2 workgroups per CU).
+// Chooses tile and split-K.  Measured on MI355X over the ResNet50 / generator shapes at 512
+// images: 64x64 tiles beat 128x128 unless the grid is several workgroups per CU deep, and
+// split-K only pays when the unsplit grid leaves CUs idle.
 int plan_conv(ConvLayer &L, int n_images, int num_cus) {
     const long M = (long)n_images * L.hm * L.wm;
-    const long target = 2L * num_cus;
     L.tile = 64;
     if (L.cout % 128 == 0) {
         const long t128 = (long)ceil_div(M, 128) * (L.cout / 128) * L.nphase;
-        if (t128 >= (3 * target) / 4) L.tile = 128;
+        if (t128 >= 4L * num_cus) L.tile = 128;
     }
     if (L.cout % L.tile != 0) return fail(GDPSO_ERR_ARG, "conv: cout must be a multiple of 64");
     const long tiles = (long)ceil_div(M, L.tile) * (L.cout / L.tile) * L.nphase;
     const long ktot = max_ktot(L);
     int splits = 1;
-    if (tiles < target) {
-        splits = (int)std::min<long>(ceil_div(target, tiles), 16);
+    if (tiles * 10 < 14L * num_cus) {
+        splits = (int)std::min<long>(ceil_div(2L * num_cus, tiles), 16);
         // keep at least 128 k per split so the prologue/epilogue stays amortised
         splits = (int)std::max<long>(1, std::min<long>(splits, ktot / 128));
     }
@@ -278,7 +338,7 @@ int launch_conv(const ConvLayer &L, hipStream_t stream, int n_images, const floa
     a.ksplit = ceil_div(ceil_div(ktot, BK), L.splits) * BK;
     a.tiles_n = L.cout / L.tile;
     a.slab = (long)n_images * L.hout * L.wout * L.cout;
-    if (L.cin % BK != 0) return fail(GDPSO_ERR_ARG, "conv: cin must be a multiple of 32");
+    if (L.cin % BK != 0 || L.cin > MAX_CIN) return fail(GDPSO_ERR_ARG, "conv: cin must be a multiple of 32, at most 4096");
     if (L.splits > 1 && !splitk_ws) return fail(GDPSO_ERR_WORKSPACE, "conv: split-K workspace missing");
     const int tiles_m = ceil_div(a.M, L.tile);
     dim3 grid(tiles_m * a.tiles_n, 1, L.nphase * L.splits);
@@ -331,5 +391,61 @@ extern "C" int gdpso_conv_timing_end(double *total_ms, int *launches, double *fl
     if (total_ms) *total_ms = ms;
     if (launches) *launches = (int)(g_timing.used / 2);
     if (flops) *flops = g_timing.flops;
+    return GDPSO_OK;
+}
+
+// Times one convolution layer in isolation (development / tuning aid): random weights and
+// inputs, `reps` back-to-back launches bracketed by HIP events.  tile = 0 / splits = 0 keep
+// the planner's choice.
+extern "C" int gdpso_conv_probe(int n_images, int hin, int cin, int cout, int ksize, int stride, int pad, int tile,
+                                int splits, int with_res, int reps, double *avg_us, int *tile_used, int *splits_used) {
+    using namespace gdpso;
+    GDPSO_REQUIRE(n_images > 0 && hin > 0 && cin % 32 == 0 && cout % 64 == 0 && reps > 0 && avg_us, "conv_probe: bad argument");
+    GDPSO_REQUIRE(tile == 0 || tile == 64 || (tile == 128 && cout % 128 == 0), "conv_probe: bad tile");
+    std::vector<float> w((size_t)cout * cin * ksize * ksize), packed, sc(cout, 1.f), sh(cout, 0.1f);
+    uint32_t st = 12345u;
+    auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 65536.f - 0.5f; };
+    for (auto &v : w) v = rnd() * 0.1f;
+    ConvLayer L;
+    make_conv(L, w.data(), cout, cin, ksize, ksize, stride, pad, hin, hin, ACT_RELU, packed);
+    DeviceArena arena;
+    int rc = upload_conv(arena, L, packed, sc, sh);
+    if (rc) return rc;
+    int dev = 0, cus = 256;
+    GDPSO_HIP(hipGetDevice(&dev));
+    GDPSO_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if ((rc = plan_conv(L, n_images, cus))) return rc;
+    if (tile) L.tile = tile;
+    if (splits) L.splits = splits;
+    const size_t in_elems = (size_t)n_images * hin * hin * cin, out_elems = (size_t)n_images * L.hout * L.wout * cout;
+    std::vector<float> hin_v(in_elems);
+    for (auto &v : hin_v) v = rnd();
+    const float *d_in = nullptr;
+    if ((rc = arena.upload(hin_v, &d_in))) return rc;
+    float *d_out = nullptr, *d_res = nullptr, *d_sk = nullptr;
+    GDPSO_HIP(hipMalloc(&d_out, out_elems * 4));
+    arena.blocks.push_back(d_out);
+    GDPSO_HIP(hipMalloc(&d_res, out_elems * 4));
+    arena.blocks.push_back(d_res);
+    GDPSO_HIP(hipMemset(d_res, 0, out_elems * 4));
+    GDPSO_HIP(hipMalloc(&d_sk, std::max<size_t>(4, conv_splitk_bytes(L, n_images))));
+    arena.blocks.push_back(d_sk);
+    hipEvent_t e0, e1;
+    GDPSO_HIP(hipEventCreate(&e0));
+    GDPSO_HIP(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i)
+        if ((rc = launch_conv(L, nullptr, n_images, d_in, with_res ? d_res : nullptr, d_out, d_sk))) return rc;
+    GDPSO_HIP(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < reps; ++i)
+        if ((rc = launch_conv(L, nullptr, n_images, d_in, with_res ? d_res : nullptr, d_out, d_sk))) return rc;
+    GDPSO_HIP(hipEventRecord(e1, nullptr));
+    GDPSO_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    GDPSO_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_us = 1e3 * ms / reps;
+    if (tile_used) *tile_used = L.tile;
+    if (splits_used) *splits_used = L.splits;
     return GDPSO_OK;
 }

@@ -225,6 +225,12 @@ int gdpso_swarm_iterate(const gdpso_swarm *s, const gdpso_generator *g, const gd
 int gdpso_conv_timing_begin(int max_launches);
 int gdpso_conv_timing_end(double *total_ms, int *launches, double *flops);
 
+/* No counterpart in the reference: times one ksize x ksize convolution layer in isolation
+ * on random data (allocates and frees its own buffers; a development / tuning aid).
+ * tile (0, 64 or 128) and splits (0 = planner's choice) override the launch plan. */
+int gdpso_conv_probe(int n_images, int hin, int cin, int cout, int ksize, int stride, int pad, int tile,
+                     int splits, int with_res, int reps, double *avg_us, int *tile_used, int *splits_used);
+
 #ifdef __cplusplus
 }
 #endif

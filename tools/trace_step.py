@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Print the per-kernel timeline of the last complete swarm iteration found in a
+rocprofv3 --kernel-trace CSV, plus per-kernel totals for that iteration.
+
+    python tools/trace_step.py gpurun_out/prof/<host>/<pid>_kernel_trace.csv [--full]
+"""
+import csv
+import sys
+from collections import defaultdict
+
+
+def main():
+    path = sys.argv[1]
+    full = "--full" in sys.argv
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    idx = [i for i, r in enumerate(rows) if "latent_prep" in r["Kernel_Name"]]
+    if len(idx) < 2:
+        raise SystemExit("fewer than two iterations in the trace")
+    s, e = idx[-2], idx[-1]
+    t0 = int(rows[s]["Start_Timestamp"])
+    prev_end = None
+    tot = defaultdict(lambda: [0, 0.0])
+    busy = 0.0
+    for r in rows[s:e]:
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("gdpso::", "")
+        st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        gap = (st - prev_end) / 1e3 if prev_end else 0.0
+        prev_end = en
+        grid = (int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Grid_Size_Z"]))
+        tot[name][0] += 1
+        tot[name][1] += (en - st) / 1e3
+        busy += (en - st) / 1e3
+        if full:
+            print(f"{(st - t0) / 1e3:9.1f}us dur {(en - st) / 1e3:7.1f}us gap {gap:5.1f} {name[:36]:36s} grid {grid}")
+    span = (int(rows[e]["Start_Timestamp"]) - t0) / 1e3
+    print(f"iteration span {span:.1f} us, kernels busy {busy:.1f} us, {e - s} launches")
+    for name, (c, t) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
+        print(f"  {t:8.1f} us  {c:3d} x  {name}")
+
+
+if __name__ == "__main__":
+    main()
