@@ -66,6 +66,7 @@ struct ConvLayer {
 // conv_gemm.hip
 int plan_conv(ConvLayer &L, int n_images, int num_cus);
 size_t conv_splitk_bytes(const ConvLayer &L, int n_images);
+int conv_splitk_prepare(hipStream_t stream, float *splitk_ws);
 int launch_conv(const ConvLayer &L, hipStream_t stream, int n_images, const float *in, const float *res,
                 float *out, float *splitk_ws);
 

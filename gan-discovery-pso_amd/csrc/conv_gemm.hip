@@ -23,6 +23,7 @@ namespace gdpso {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 
 constexpr int BK = 32;
 constexpr int LDA = BK + 4;  // 144-byte rows: ds_read_b128 of 16 consecutive rows is conflict-free
@@ -36,6 +37,7 @@ struct ConvKArgs {
     const float *res;
     float *out;
     float *part;       // split-K slabs [splits][pixels][cout], or null
+    int *counters;     // split-K arrival counters, one per output tile (zero between launches), or null
     const int *table;  // [nphase][PHASE_TABLE_INTS]
     int M, hm, wm;
     int hin, win, cin;
@@ -225,31 +227,88 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKArgs a) {
     __syncthreads();
     constexpr int C4 = BN / 4;     // float4 per tile row
     constexpr int RPP = 256 / C4;  // tile rows per pass
+    constexpr int PASSES = BM / RPP;
     const int c4 = tid % C4, r0 = tid / C4;
     const int col = n0 + c4 * 4;
     const bool direct = a.splits == 1;
-    float *dst = direct ? a.out : a.part + (size_t)sp * a.slab;
     const f32x4 sc = *(const f32x4 *)(a.scale + col), sh = *(const f32x4 *)(a.shift + col);
     const bool remap = a.out_mul != 1 || a.hm != a.hout || a.wm != a.wout;
-#pragma unroll 4
-    for (int pass = 0; pass < BM / RPP; ++pass) {
-        const int row = pass * RPP + r0, m = m0 + row;
-        if (m >= a.M) continue;
+    // element offset of this thread's 4 channels in each of its rows (-1: row past M)
+    long off[PASSES];
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass) {
+        const int m = m0 + pass * RPP + r0;
         size_t pix = (size_t)m;
-        if (remap) {
+        if (remap && m < a.M) {
             const int n = m / hw, rr = m - n * hw;
             const int my = rr / a.wm, mx = rr - my * a.wm;
             pix = ((size_t)n * a.hout + my * a.out_mul + off_y) * a.wout + mx * a.out_mul + off_x;
         }
-        const size_t o = pix * a.cout + col;
-        f32x4 v = *(const f32x4 *)&sC[row * LDC + c4 * 4];
-        if (direct) {
+        off[pass] = m < a.M ? (long)(pix * a.cout + col) : -1;
+    }
+    if (direct) {
+#pragma unroll
+        for (int pass = 0; pass < PASSES; ++pass) {
+            if (off[pass] < 0) continue;
+            f32x4 v = *(const f32x4 *)&sC[(pass * RPP + r0) * LDC + c4 * 4];
             v = v * sc + sh;
-            if (a.res) v += *(const f32x4 *)(a.res + o);
+            if (a.res) v += *(const f32x4 *)(a.res + off[pass]);
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = apply_act(v[q], a.act);
+            *(f32x4 *)(a.out + off[pass]) = v;
         }
-        *(f32x4 *)(dst + o) = v;
+        return;
+    }
+
+    // Split-K: every split writes its partial tile to its slab; the workgroup that arrives
+    // last at the tile's counter sums the slabs in split order (so the result does not
+    // depend on who is last) and applies the epilogue.  Hand-off: write-through (sc1) 16-byte
+    // slab stores, which need no L2 write-back; every wave drains its stores; workgroup
+    // barrier; one lane adds to the counter.  The last arriver takes one agent-scope acquire
+    // (drops this CU's stale L1 lines) before anyone loads.
+    float *slab = a.part + (size_t)sp * a.slab;
+    if (a.counters == nullptr) {  // reduction by the separate kernel
+#pragma unroll
+        for (int pass = 0; pass < PASSES; ++pass)
+            if (off[pass] >= 0) *(f32x4 *)(slab + off[pass]) = *(const f32x4 *)&sC[(pass * RPP + r0) * LDC + c4 * 4];
+        return;
+    }
+    {
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(slab, 0, (int)(a.slab * 4), 0x00020000);
+#pragma unroll
+        for (int pass = 0; pass < PASSES; ++pass)
+            if (off[pass] >= 0)
+                __builtin_amdgcn_raw_buffer_store_b128(
+                    __builtin_bit_cast(u32x4, *(const f32x4 *)&sC[(pass * RPP + r0) * LDC + c4 * 4]), rsrc,
+                    (int)(off[pass] * 4), 0, 16 /* sc1 */);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int *s_last = (int *)&lds[2 * (BM + BN) * LDA - 4];  // past the output tile
+    if (tid == 0) {
+        int *cnt = a.counters + ph * nt + tile;
+        const int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = ticket == a.splits - 1;
+        if (last) {
+            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        *s_last = last;
+    }
+    __syncthreads();
+    if (!*s_last) return;
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass) {
+        if (off[pass] < 0) continue;
+        f32x4 v = *(const f32x4 *)(a.part + off[pass]);
+#pragma unroll 4
+        for (int k = 1; k < a.splits; ++k) v += *(const f32x4 *)(a.part + (size_t)k * a.slab + off[pass]);
+        v = v * sc + sh;
+        if (a.res) v += *(const f32x4 *)(a.res + off[pass]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = apply_act(v[q], a.act);
+        *(f32x4 *)(a.out + off[pass]) = v;
     }
 }
 
@@ -318,16 +377,29 @@ int plan_conv(ConvLayer &L, int n_images, int num_cus) {
     return GDPSO_OK;
 }
 
+// Split-K workspace: [SPLITK_COUNTER_BYTES of arrival counters][splits slabs].
+constexpr size_t SPLITK_COUNTER_BYTES = 16384;
 size_t conv_splitk_bytes(const ConvLayer &L, int n_images) {
-    if (L.splits <= 1) return 0;
-    return (size_t)L.splits * n_images * L.hout * L.wout * L.cout * sizeof(float);
+    if (L.splits <= 1) return SPLITK_COUNTER_BYTES;
+    return SPLITK_COUNTER_BYTES + (size_t)L.splits * n_images * L.hout * L.wout * L.cout * sizeof(float);
+}
+
+// Zeroes the arrival counters; once per forward pass, ahead of the first convolution.
+int conv_splitk_prepare(hipStream_t stream, float *splitk_ws) {
+    GDPSO_HIP(hipMemsetAsync(splitk_ws, 0, SPLITK_COUNTER_BYTES, stream));
+    return GDPSO_OK;
 }
 
 int launch_conv(const ConvLayer &L, hipStream_t stream, int n_images, const float *in, const float *res,
                 float *out, float *splitk_ws) {
     ConvKArgs a;
     a.in = in; a.wt = L.wt; a.scale = L.scale; a.shift = L.shift; a.res = res; a.out = out;
-    a.part = L.splits > 1 ? splitk_ws : nullptr;
+    const int tiles_total = ceil_div((long)n_images * L.hm * L.wm, L.tile) * (L.cout / L.tile) * L.nphase;
+    // measured: the in-kernel (last-arriver) reduction beats the separate reduce kernel up to
+    // 4 splits; beyond that the last arriver's serial slab reads cost more than a launch
+    const bool fused_reduce = L.splits > 1 && L.splits <= 4 && (size_t)tiles_total * sizeof(int) <= SPLITK_COUNTER_BYTES;
+    a.part = L.splits > 1 ? splitk_ws + SPLITK_COUNTER_BYTES / sizeof(float) : nullptr;
+    a.counters = fused_reduce ? (int *)splitk_ws : nullptr;
     a.table = L.table;
     a.M = n_images * L.hm * L.wm; a.hm = L.hm; a.wm = L.wm;
     a.hin = L.hin; a.win = L.win; a.cin = L.cin;
@@ -340,6 +412,7 @@ int launch_conv(const ConvLayer &L, hipStream_t stream, int n_images, const floa
     a.slab = (long)n_images * L.hout * L.wout * L.cout;
     if (L.cin % BK != 0 || L.cin > MAX_CIN) return fail(GDPSO_ERR_ARG, "conv: cin must be a multiple of 32, at most 4096");
     if (L.splits > 1 && !splitk_ws) return fail(GDPSO_ERR_WORKSPACE, "conv: split-K workspace missing");
+    if (a.slab * 4 >= (1L << 31)) return fail(GDPSO_ERR_ARG, "conv: output larger than 2 GiB");
     const int tiles_m = ceil_div(a.M, L.tile);
     dim3 grid(tiles_m * a.tiles_n, 1, L.nphase * L.splits);
     const bool timed = g_timing.on && g_timing.used + 2 <= g_timing.events.size();
@@ -353,7 +426,7 @@ int launch_conv(const ConvLayer &L, hipStream_t stream, int n_images, const floa
         g_timing.used += 2;
         g_timing.flops += L.flops_nominal * n_images;
     }
-    if (L.splits > 1) {
+    if (L.splits > 1 && !fused_reduce) {
         const long quads = a.slab / 4;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ceil_div(quads, 256)), dim3(256), 0, stream, a.part, L.splits,
                            a.slab, L.cout, L.scale, L.shift, res, out, L.act);
@@ -430,6 +503,7 @@ extern "C" int gdpso_conv_probe(int n_images, int hin, int cin, int cout, int ks
     GDPSO_HIP(hipMemset(d_res, 0, out_elems * 4));
     GDPSO_HIP(hipMalloc(&d_sk, std::max<size_t>(4, conv_splitk_bytes(L, n_images))));
     arena.blocks.push_back(d_sk);
+    if ((rc = conv_splitk_prepare(nullptr, d_sk))) return rc;
     hipEvent_t e0, e1;
     GDPSO_HIP(hipEventCreate(&e0));
     GDPSO_HIP(hipEventCreate(&e1));

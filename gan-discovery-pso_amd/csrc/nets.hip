@@ -27,64 +27,85 @@ __global__ __launch_bounds__(256) void latent_prep_kernel(const void *__restrict
 // (reference src/utils/util_dcgan.py:137-138), per-image min/max rescale to [0,1]
 // (src/utils/util_data.py:129-135 on a batch of one) and, optionally, the pixel MSE
 // against a target image (src/pso/util_discovery.py:97).
-// One workgroup per image.  16 lanes share one output pixel (4 channels each, float4
-// loads of the NHWC input), so a wave produces 4 pixels per pass.
+// One workgroup per image.  The NHWC input image is staged in LDS once (when it fits);
+// the four output phases (oy&1, ox&1) are processed one after the other so that the
+// 2x2 kernel taps of a phase are wave-uniform and live in registers.  16 lanes share one
+// output pixel (4 channels each, one 16-byte read per tap) and reduce by shuffles.
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+template <bool STAGED>
 __global__ __launch_bounds__(256) void gen_last_kernel(const float *__restrict__ a2, const float *__restrict__ w5,
                                                        float bias, int hin, int cin, float *__restrict__ img,
                                                        float *__restrict__ img01, const float *__restrict__ target,
                                                        float *__restrict__ mse) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int side = 2 * hin, npix = side * side;
-    float *s_w = smem;               // [16][cin]
-    float *s_img = smem + 16 * cin;  // [npix]
-    float *s_red = s_img + npix;     // [12]: min, max, squared error of the 4 waves
+    const int side = 2 * hin, npix = side * side, nin = hin * hin;
+    float *s_img = smem;            // [npix]
+    float *s_red = s_img + npix;    // [16]: min, max, squared error of the 4 waves
+    float *s_a2 = s_red + 16;       // [nin][cin] when STAGED
     const int tid = threadIdx.x, n = blockIdx.x;
-    for (int i = tid; i < 16 * cin; i += 256) s_w[i] = w5[i];
-    __syncthreads();
+    const float *src = a2 + (size_t)n * nin * cin;
+    if (STAGED) {
+        for (int i = tid * 4; i < nin * cin; i += 1024) *(f32x4 *)&s_a2[i] = *(const f32x4 *)&src[i];
+        __syncthreads();
+    }
+    const float *act = STAGED ? s_a2 : src;
     const int grp = tid >> 4, sub = tid & 15;
-    const float *src = a2 + (size_t)n * hin * hin * cin;
-    for (int p0 = 0; p0 < npix; p0 += 16) {
-        const int p = p0 + grp;
-        float acc = 0.f;
-        if (p < npix) {
-            const int oy = p / side, ox = p - oy * side;
-            const int py = oy & 1, px = ox & 1, my = oy >> 1, mx = ox >> 1;
+    for (int ph = 0; ph < 4; ++ph) {
+        const int py = ph >> 1, px = ph & 1;
+        // taps of this phase: (input offset, kernel index) = (0, 1), (-1, 3) for even rows; (0, 2), (+1, 0) for odd
+        const int dy1 = py ? 1 : -1, ky0 = py ? 2 : 1, ky1 = py ? 0 : 3;
+        const int dx1 = px ? 1 : -1, kx0 = px ? 2 : 1, kx1 = px ? 0 : 3;
+        for (int c0 = 0; c0 < cin; c0 += 64) {
+            const int c = c0 + sub * 4;
+            const bool cok = c < cin;
+            f32x4 w00 = 0.f, w01 = 0.f, w10 = 0.f, w11 = 0.f;
+            if (cok) {
+                w00 = *(const f32x4 *)&w5[(ky0 * 4 + kx0) * cin + c];
+                w01 = *(const f32x4 *)&w5[(ky0 * 4 + kx1) * cin + c];
+                w10 = *(const f32x4 *)&w5[(ky1 * 4 + kx0) * cin + c];
+                w11 = *(const f32x4 *)&w5[(ky1 * 4 + kx1) * cin + c];
+            }
+            for (int q0 = 0; q0 < nin; q0 += 16) {
+                const int q = q0 + grp;
+                float acc = 0.f;
+                if (q < nin && cok) {
+                    const int my = q / hin, mx = q - my * hin;
+                    const int iy1 = my + dy1, ix1 = mx + dx1;
+                    const bool yok = (unsigned)iy1 < (unsigned)hin, xok = (unsigned)ix1 < (unsigned)hin;
+                    const f32x4 z = 0.f;
+                    const f32x4 v00 = *(const f32x4 *)&act[(size_t)(my * hin + mx) * cin + c];
+                    const f32x4 v01 = xok ? *(const f32x4 *)&act[(size_t)(my * hin + ix1) * cin + c] : z;
+                    const f32x4 v10 = yok ? *(const f32x4 *)&act[(size_t)(iy1 * hin + mx) * cin + c] : z;
+                    const f32x4 v11 = (yok && xok) ? *(const f32x4 *)&act[(size_t)(iy1 * hin + ix1) * cin + c] : z;
 #pragma unroll
-            for (int ty = 0; ty < 2; ++ty) {
-                const int iy = my + (ty == 0 ? 0 : (py ? 1 : -1));
-                const int ky = py ? (ty == 0 ? 2 : 0) : (ty == 0 ? 1 : 3);
-                if ((unsigned)iy >= (unsigned)hin) continue;
-#pragma unroll
-                for (int tx = 0; tx < 2; ++tx) {
-                    const int ix = mx + (tx == 0 ? 0 : (px ? 1 : -1));
-                    const int kx = px ? (tx == 0 ? 2 : 0) : (tx == 0 ? 1 : 3);
-                    if ((unsigned)ix >= (unsigned)hin) continue;
-                    const float *row = src + (size_t)(iy * hin + ix) * cin;
-                    const float *wr = s_w + (ky * 4 + kx) * cin;
-                    for (int c = sub * 4; c < cin; c += 64) {
-                        const float4 v = *(const float4 *)(row + c);
-                        const float4 w = *(const float4 *)(wr + c);
-                        acc = fmaf(v.x, w.x, acc);
-                        acc = fmaf(v.y, w.y, acc);
-                        acc = fmaf(v.z, w.z, acc);
-                        acc = fmaf(v.w, w.w, acc);
+                    for (int k = 0; k < 4; ++k) {
+                        acc = fmaf(v00[k], w00[k], acc);
+                        acc = fmaf(v01[k], w01[k], acc);
+                        acc = fmaf(v10[k], w10[k], acc);
+                        acc = fmaf(v11[k], w11[k], acc);
                     }
+                }
+                acc += __shfl_xor(acc, 8, 16);
+                acc += __shfl_xor(acc, 4, 16);
+                acc += __shfl_xor(acc, 2, 16);
+                acc += __shfl_xor(acc, 1, 16);
+                if (sub == 0 && q < nin) {
+                    const int my = q / hin, mx = q - my * hin;
+                    const int o = (2 * my + py) * side + 2 * mx + px;
+                    s_img[o] = c0 == 0 ? acc : s_img[o] + acc;
                 }
             }
         }
-        acc += __shfl_xor(acc, 8, 16);
-        acc += __shfl_xor(acc, 4, 16);
-        acc += __shfl_xor(acc, 2, 16);
-        acc += __shfl_xor(acc, 1, 16);
-        if (sub == 0 && p < npix) s_img[p] = tanhf(acc + bias);
     }
     __syncthreads();
-    // per-image min / max: wavefront shuffle reduction, then across the 4 waves
+    // bias + tanh, then the per-image min / max: wavefront shuffle reduction, then across the 4 waves
     float mn = INFINITY, mx = -INFINITY, se = 0.f;
     float *dst = img ? img + (size_t)n * npix : nullptr;
     const float *tg = target ? target + (size_t)n * npix : nullptr;
     for (int i = tid; i < npix; i += 256) {
-        const float v = s_img[i];
+        const float v = tanhf(s_img[i] + bias);
+        s_img[i] = v;
         mn = fminf(mn, v);
         mx = fmaxf(mx, v);
         if (dst) dst[i] = v;
@@ -109,7 +130,7 @@ __global__ __launch_bounds__(256) void gen_last_kernel(const float *__restrict__
     mx = fmaxf(fmaxf(s_red[4], s_red[5]), fmaxf(s_red[6], s_red[7]));
     const float range = mx - mn;
     float *d01 = img01 + (size_t)n * npix;
-    for (int i = tid; i < npix; i += 256) d01[i] = (s_img[i] - mn) / range;
+    for (int i = tid; i < npix; i += 256) d01[i] = (s_img[i] - mn) / range;  // each thread rescales the pixels it wrote
     if (mse && tid == 0) mse[n] = ((s_red[8] + s_red[9]) + (s_red[10] + s_red[11])) / (float)npix;
 }
 
@@ -117,22 +138,24 @@ __global__ __launch_bounds__(256) void gen_last_kernel(const float *__restrict__
 // Assessor stem, fused: Conv2d(1 -> 64, k7, s2, p3, no bias) + BatchNorm + ReLU +
 // MaxPool2d(3, s2, p1) (reference src/pso/util_cnn.py:85-88, 103-106).  NHWC output.
 // Grid (image, band of pooled rows).  Lane = output channel (its 49 weights live in
-// registers); the four waves take conv pixels round-robin, reading the zero-padded image
-// from LDS as wave-wide broadcasts.  Conv rows of the band stay in LDS for the pooling.
+// registers); the four waves take PAIRS of horizontally adjacent conv pixels round-robin:
+// the two 7-wide windows of a pair span 9 input pixels, read from the zero-padded image
+// in LDS as three wave-wide broadcast 16-byte reads per kernel row (row stride and window
+// start are multiples of 4 floats).  Conv rows of the band stay in LDS for the pooling.
 __global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ img01, const float *__restrict__ w,
                                                    const float *__restrict__ scale, const float *__restrict__ shift,
-                                                   int side, int ho, int hp, int band, float *__restrict__ out) {
+                                                   int side, int ho, int hp, int band, int ps, float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int pside = side + 6;
-    float *s_img = smem;                   // [(side+6)^2], zero border of 3
-    float *s_conv = smem + pside * pside;  // [(2*band+1)][ho][64]
+    const int prows = side + 6;
+    float *s_img = smem;                // [side+6][ps], zero border of 3 on the left/top
+    float *s_conv = smem + prows * ps;  // [(2*band+1)][ho][64]
     const int tid = threadIdx.x, c = tid & 63, q = tid >> 6;
     const int n = blockIdx.x, pr0 = blockIdx.y * band;
     const int pr1 = min(hp, pr0 + band);
     const int cr0 = 2 * pr0 - 1, cr1 = 2 * (pr1 - 1) + 1;  // conv rows needed (may stick out)
     const float *src = img01 + (size_t)n * side * side;
-    for (int i = tid; i < pside * pside; i += 256) {
-        const int y = i / pside - 3, x = i % pside - 3;
+    for (int i = tid; i < prows * ps; i += 256) {
+        const int y = i / ps - 3, x = i % ps - 3;
         s_img[i] = ((unsigned)y < (unsigned)side && (unsigned)x < (unsigned)side) ? src[y * side + x] : 0.f;
     }
     float wreg[49];
@@ -140,20 +163,30 @@ __global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ img
     for (int t = 0; t < 49; ++t) wreg[t] = w[t * 64 + c];
     const float sc = scale[c], sh = shift[c];
     __syncthreads();
-    const int rows = cr1 - cr0 + 1;
-    for (int p = q; p < rows * ho; p += 4) {
-        const int r = p / ho, cx = p - r * ho, cy = cr0 + r;
-        float v = 0.f;
+    const int rows = cr1 - cr0 + 1, pairs = (ho + 1) >> 1;
+    for (int p = q; p < rows * pairs; p += 4) {
+        const int r = p / pairs, cx = 2 * (p - r * pairs), cy = cr0 + r;
+        float v0 = 0.f, v1 = 0.f;
         if ((unsigned)cy < (unsigned)ho) {
-            const float *base = s_img + (2 * cy) * pside + 2 * cx;  // padded coords: +3 - 3
-            float acc = 0.f;
+            const float *base = s_img + (2 * cy) * ps + 2 * cx;  // padded coordinates: +3 - 3
+            float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-            for (int ky = 0; ky < 7; ++ky)
+            for (int ky = 0; ky < 7; ++ky) {
+                const f32x4 x0 = *(const f32x4 *)(base + ky * ps);
+                const f32x4 x1 = *(const f32x4 *)(base + ky * ps + 4);
+                const f32x4 x2 = *(const f32x4 *)(base + ky * ps + 8);
+                const float xs[12] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3], x2[0], x2[1], x2[2], x2[3]};
 #pragma unroll
-                for (int kx = 0; kx < 7; ++kx) acc = fmaf(base[ky * pside + kx], wreg[ky * 7 + kx], acc);
-            v = fmaxf(acc * sc + sh, 0.f);
+                for (int kx = 0; kx < 7; ++kx) {
+                    a0 = fmaf(xs[kx], wreg[ky * 7 + kx], a0);
+                    a1 = fmaf(xs[kx + 2], wreg[ky * 7 + kx], a1);
+                }
+            }
+            v0 = fmaxf(a0 * sc + sh, 0.f);
+            v1 = fmaxf(a1 * sc + sh, 0.f);
         }
-        s_conv[p * 64 + c] = v;
+        s_conv[(r * ho + cx) * 64 + c] = v0;
+        if (cx + 1 < ho) s_conv[(r * ho + cx + 1) * 64 + c] = v1;
     }
     __syncthreads();
     for (int p = q; p < (pr1 - pr0) * hp; p += 4) {
@@ -404,11 +437,16 @@ extern "C" int gdpso_generator_forward(const gdpso_generator *g, void *stream_, 
     const long ne = (long)n * g->kpad;
     hipLaunchKernelGGL(latent_prep_kernel, dim3(ceil_div(ne, 256)), dim3(256), 0, stream, z, z_is_f64, n, g->z_dim, g->kpad, zpad);
     int rc;
+    if ((rc = conv_splitk_prepare(stream, sk))) return rc;
     if ((rc = launch_conv(l1, stream, n, zpad, nullptr, a1, sk))) return rc;
     if ((rc = launch_conv(l2, stream, n, a1, nullptr, a2, sk))) return rc;
     const int hin = 2 * g->k1;
-    const size_t smem = ((size_t)16 * g->features + (size_t)g->side * g->side + 16) * sizeof(float);
-    hipLaunchKernelGGL(gen_last_kernel, dim3(n), dim3(256), smem, stream, a2, g->w5, g->b5, hin, g->features, img, img01, target, mse);
+    const size_t base = ((size_t)g->side * g->side + 16) * sizeof(float);
+    const size_t staged = base + (size_t)hin * hin * g->features * sizeof(float);
+    if (staged <= 64 * 1024)
+        hipLaunchKernelGGL(gen_last_kernel<true>, dim3(n), dim3(256), staged, stream, a2, g->w5, g->b5, hin, g->features, img, img01, target, mse);
+    else
+        hipLaunchKernelGGL(gen_last_kernel<false>, dim3(n), dim3(256), base, stream, a2, g->w5, g->b5, hin, g->features, img, img01, target, mse);
     GDPSO_HIP(hipGetLastError());
     return GDPSO_OK;
 }
@@ -420,7 +458,7 @@ struct Bottleneck {
 };
 
 struct gdpso_assessor {
-    int n_class, side, ho, hp, stem_band;
+    int n_class, side, ho, hp, stem_band, stem_ps;
     const float *stem_w, *stem_scale, *stem_shift;
     std::vector<Bottleneck> blocks;
     const float *fc_w, *fc_b;
@@ -486,7 +524,8 @@ extern "C" int gdpso_assessor_create_resnet(gdpso_assessor **out, const int dept
     // pooled rows per stem workgroup: conv rows of the band must fit 64 KiB of LDS
     {
         const size_t row_bytes = (size_t)a->ho * 64 * 4;
-        const size_t avail = (size_t)64 * 1024 - (size_t)(img_side + 6) * (img_side + 6) * 4;
+        a->stem_ps = (2 * a->ho + 12 + 3) / 4 * 4;  // padded row: the last pair's window reads up to 2*ho + 9
+        const size_t avail = (size_t)64 * 1024 - (size_t)(img_side + 6) * a->stem_ps * 4;
         const int max_rows = (int)std::max<size_t>(3, avail / row_bytes);
         a->stem_band = std::max(1, std::min(a->hp, (max_rows - 1) / 2));
     }
@@ -569,12 +608,13 @@ extern "C" int gdpso_assessor_forward(const gdpso_assessor *a, void *stream_, in
     float *sc = (float *)(ws + L.sc), *sk = (float *)(ws + L.splitk);
     {
         const int rows = 2 * a->stem_band + 1;
-        const size_t smem = ((size_t)(a->side + 6) * (a->side + 6) + (size_t)rows * a->ho * 64) * sizeof(float);
+        const size_t smem = ((size_t)(a->side + 6) * a->stem_ps + (size_t)rows * a->ho * 64) * sizeof(float);
         dim3 grid(n, ceil_div(a->hp, a->stem_band));
         hipLaunchKernelGGL(stem_kernel, grid, dim3(256), smem, stream, img01, a->stem_w, a->stem_scale, a->stem_shift, a->side,
-                           a->ho, a->hp, a->stem_band, x);
+                           a->ho, a->hp, a->stem_band, a->stem_ps, x);
     }
     int rc;
+    if ((rc = conv_splitk_prepare(stream, sk))) return rc;
     for (const Bottleneck &b : L.blocks) {
         if ((rc = launch_conv(b.c1, stream, n, x, nullptr, t1, sk))) return rc;
         if ((rc = launch_conv(b.c2, stream, n, t1, nullptr, t2, sk))) return rc;
@@ -669,6 +709,7 @@ extern "C" int gdpso_encoder_forward(const gdpso_encoder *e, void *stream_, int 
     float *a1 = (float *)(ws + L.a1), *a2 = (float *)(ws + L.a2), *lat = (float *)(ws + L.lat), *sk = (float *)(ws + L.splitk);
     hipLaunchKernelGGL(enc_first_kernel, dim3(n), dim3(256), 30 * 30 * sizeof(float), stream, img, e->w1, e->b1, 28, 14, e->features, a1);
     int rc;
+    if ((rc = conv_splitk_prepare(stream, sk))) return rc;
     if ((rc = launch_conv(c2, stream, n, a1, nullptr, a2, sk))) return rc;
     if ((rc = launch_conv(c3, stream, n, a2, nullptr, lat, sk))) return rc;
     hipLaunchKernelGGL(slice_cols_kernel, dim3(ceil_div((long)n * e->enc_dim, 256)), dim3(256), 0, stream, lat, e->out_pad, n,
