@@ -51,6 +51,7 @@ class RunDesc(C.Structure):
 _PROTOTYPES = {
     "gdpso_abi_version": (c_int, []),
     "gdpso_last_error": (C.c_char_p, []),
+    "gdpso_struct_size": (c_size_t, [c_int]),
     "gdpso_generator_create": (c_int, [C.POINTER(c_void_p), c_int, c_int, c_int, FloatPP, c_int]),
     "gdpso_generator_destroy": (None, [c_void_p]),
     "gdpso_generator_image_side": (c_int, [c_void_p]),
@@ -102,6 +103,8 @@ def lib():
             fn.restype, fn.argtypes = res, args
         if handle.gdpso_abi_version() != ABI_VERSION:
             raise GdpsoError("libgdpso.so ABI version mismatch: rebuild the library")
+        if handle.gdpso_struct_size(0) != C.sizeof(SwarmDesc) or handle.gdpso_struct_size(1) != C.sizeof(RunDesc):
+            raise GdpsoError("struct layout mismatch between _lib.py and libgdpso.so")
         _lib = handle
     return _lib
 

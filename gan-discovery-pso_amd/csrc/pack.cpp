@@ -151,4 +151,5 @@ int upload_conv(DeviceArena &arena, ConvLayer &L, const std::vector<float> &pack
 extern "C" {
 int gdpso_abi_version(void) { return GDPSO_ABI_VERSION; }
 const char *gdpso_last_error(void) { return gdpso::last_error_cstr(); }
+size_t gdpso_struct_size(int which) { return which == 0 ? sizeof(gdpso_swarm) : which == 1 ? sizeof(gdpso_run) : 0; }
 }

@@ -423,14 +423,14 @@ class TorchComm:
 
     def all_gather(self, out: torch.Tensor, inp: torch.Tensor):
         # out [W, d+2] is the swarm's candidate table; inp is this rank's row of it
-        self.dist.all_gather_into_tensor(out, inp.clone(), group=self.group)
+        self.dist.all_gather_into_tensor(out.view(-1), inp.clone().view(-1), group=self.group)
 
     def gather_positions(self, pos: torch.Tensor, n_global: int) -> torch.Tensor:
         n_max = -(-n_global // self.world)
         pad = torch.zeros(n_max, pos.shape[1], dtype=pos.dtype, device=pos.device)
         pad[:pos.shape[0]] = pos
         allp = torch.empty(self.world * n_max, pos.shape[1], dtype=pos.dtype, device=pos.device)
-        self.dist.all_gather_into_tensor(allp, pad, group=self.group)
+        self.dist.all_gather_into_tensor(allp.view(-1), pad.view(-1), group=self.group)
         if n_global == self.world * n_max:
             return allp
         rows = []

@@ -39,6 +39,9 @@ extern "C" {
 
 int gdpso_abi_version(void);
 const char *gdpso_last_error(void);
+/* sizeof(gdpso_swarm) for which = 0, sizeof(gdpso_run) for which = 1, else 0: lets a foreign
+ * binding check its struct layouts against the library's. */
+size_t gdpso_struct_size(int which);
 
 /* ------------------------------------------------------------------ generator
  * Replaces Generator.forward, reference src/utils/util_dcgan.py:128-149 (identical copies
