@@ -77,12 +77,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # GDPSO_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the multi-rank path
+    backend = os.environ.get("GDPSO_BENCH_BACKEND", "nccl")
+    local_rank %= max(1, torch.cuda.device_count()) if backend != "nccl" else 1 << 30
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     comm = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     eng = importlib.import_module("gan-discovery-pso_amd.engine")
     synth = importlib.import_module("gan-discovery-pso_amd.synth")
@@ -104,17 +110,32 @@ def main():
     r = rs.standard_normal((n_global, 2, z_dim))
     sw.load(r[lo:lo + p, 0], (r[lo:lo + p, 1] - 0.5) / 10, 0.73)
 
+    if os.environ.get("GDPSO_BENCH_DEBUG"):
+        import faulthandler
+        faulthandler.dump_traceback_later(25, exit=True)
+
+    def dbg(msg):
+        if os.environ.get("GDPSO_BENCH_DEBUG"):
+            print(f"[rank {rank}] {msg}", file=sys.stderr, flush=True)
+
     def run(first, count):
+        dbg(f"run {first}..{first + count - 1}")
         if comm is None:
             sw.iterate(first, count, spec, 1.496, 1.496, False, False, 1e-5, True, seed=42)
         else:
+            deep = bool(os.environ.get("GDPSO_BENCH_DEBUG"))
             for i in range(first, first + count):
                 sw.evaluate(i, spec)
+                if deep: torch.cuda.synchronize(dev); dbg(f"{i} evaluate ok")
                 sw.local_best(i)
+                if deep: torch.cuda.synchronize(dev); dbg(f"{i} local_best ok")
                 comm.all_gather(sw.cand, sw.cand[sw.rank])
+                if deep: torch.cuda.synchronize(dev); dbg(f"{i} all_gather ok")
                 sw.global_best(i, False, False, 1e-5)
                 sw.move(i, 1.496, 1.496, seed=42)
+                if deep: torch.cuda.synchronize(dev); dbg(f"{i} move ok")
                 sw.mean_distance(i, comm.gather_positions(sw.pos, n_global))
+                if deep: torch.cuda.synchronize(dev); dbg(f"{i} distance ok")
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -123,7 +144,9 @@ def main():
             torch.cuda.synchronize(dev)
 
     run(1, w)
+    dbg("warm-up enqueued")
     fence()
+    dbg("warm-up done")
     t0 = time.perf_counter()
     run(w + 1, k)
     fence()
@@ -132,6 +155,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         comm.dist.all_reduce(t, op=comm.dist.ReduceOp.MAX)
         dt = float(t.item())
+    dbg("timed region done")
     ctrl = sw.control()
     assert int(ctrl[lib.CTRL_ITERS_DONE]) == w + k, "the loop did not run every iteration"
 

@@ -17,6 +17,8 @@
 // BK = 32, two LDS buffers, register prefetch of the next K-tile, one barrier per K-tile.
 // Small-M layers (late ResNet stages at 1x1..4x4) use 64x64 tiles plus split-K over
 // blockIdx.z with fp32 partial slabs and a fused reduce+epilogue kernel.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace gdpso {
@@ -58,6 +60,120 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == ACT_RELU) return v > 0.f ? v : 0.f;
     if (act == ACT_LEAKY02) return v > 0.f ? v : 0.2f * v;
     return v;
+}
+
+// Epilogue shared by the convolution kernels.  `lds` is the workgroup's whole LDS array
+// (lds_floats long); every operand read from it must have been retired by a barrier.
+template <int BM, int BN>
+__device__ __forceinline__ void conv_epilogue(const ConvKArgs &a, float *lds, int lds_floats,
+                                              f32x16 (&acc)[BM / 64][BN / 64], int tid, int m0, int n0, int ph, int sp,
+                                              int nt, int tile, int off_y, int off_x) {
+    constexpr int WM = BM / 64, WN = BN / 64;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int hw = a.hm * a.wm;
+    // Epilogue through LDS.  Accumulator register r of lane l is
+    // C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]; the tile is first laid out row-major
+    // in LDS (the K loop's last barrier has retired every operand read), then written with
+    // 16-byte stores: one wave instruction covers whole 256/512-byte row segments, and the
+    // residual is read the same way.
+    constexpr int LDC = BN + 4;
+    
+    float *sC = lds;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                sC[(wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDC + wc * (BN / 2) + j * 32 + l31] = acc[i][j][r];
+    __syncthreads();
+    constexpr int C4 = BN / 4;     // float4 per tile row
+    constexpr int RPP = 256 / C4;  // tile rows per pass
+    constexpr int PASSES = BM / RPP;
+    const int c4 = tid % C4, r0 = tid / C4;
+    const int col = n0 + c4 * 4;
+    const bool direct = a.splits == 1;
+    const f32x4 sc = *(const f32x4 *)(a.scale + col), sh = *(const f32x4 *)(a.shift + col);
+    const bool remap = a.out_mul != 1 || a.hm != a.hout || a.wm != a.wout;
+    // element offset of this thread's 4 channels in each of its rows (-1: row past M)
+    long off[PASSES];
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass) {
+        const int m = m0 + pass * RPP + r0;
+        size_t pix = (size_t)m;
+        if (remap && m < a.M) {
+            const int n = m / hw, rr = m - n * hw;
+            const int my = rr / a.wm, mx = rr - my * a.wm;
+            pix = ((size_t)n * a.hout + my * a.out_mul + off_y) * a.wout + mx * a.out_mul + off_x;
+        }
+        off[pass] = m < a.M ? (long)(pix * a.cout + col) : -1;
+    }
+    if (direct) {
+#pragma unroll
+        for (int pass = 0; pass < PASSES; ++pass) {
+            if (off[pass] < 0) continue;
+            f32x4 v = *(const f32x4 *)&sC[(pass * RPP + r0) * LDC + c4 * 4];
+            v = v * sc + sh;
+            if (a.res) v += *(const f32x4 *)(a.res + off[pass]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = apply_act(v[q], a.act);
+            *(f32x4 *)(a.out + off[pass]) = v;
+        }
+        return;
+    }
+
+    // Split-K: every split writes its partial tile to its slab; the workgroup that arrives
+    // last at the tile's counter sums the slabs in split order (so the result does not
+    // depend on who is last) and applies the epilogue.  Hand-off: write-through (sc1) 16-byte
+    // slab stores, which need no L2 write-back; every wave drains its stores; workgroup
+    // barrier; one lane adds to the counter.  The last arriver takes one agent-scope acquire
+    // (drops this CU's stale L1 lines) before anyone loads.
+    float *slab = a.part + (size_t)sp * a.slab;
+    if (a.counters == nullptr) {  // reduction by the separate kernel
+#pragma unroll
+        for (int pass = 0; pass < PASSES; ++pass)
+            if (off[pass] >= 0) *(f32x4 *)(slab + off[pass]) = *(const f32x4 *)&sC[(pass * RPP + r0) * LDC + c4 * 4];
+        return;
+    }
+    {
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(slab, 0, (int)(a.slab * 4), 0x00020000);
+#pragma unroll
+        for (int pass = 0; pass < PASSES; ++pass)
+            if (off[pass] >= 0)
+                __builtin_amdgcn_raw_buffer_store_b128(
+                    __builtin_bit_cast(u32x4, *(const f32x4 *)&sC[(pass * RPP + r0) * LDC + c4 * 4]), rsrc,
+                    (int)(off[pass] * 4), 0, 16 /* sc1 */);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int *s_last = (int *)&lds[lds_floats - 4];  // past the output tile
+    if (tid == 0) {
+        int *cnt = a.counters + ph * nt + tile;
+        const int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = ticket == a.splits - 1;
+        if (last) {
+            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        *s_last = last;
+    }
+    __syncthreads();
+    if (!*s_last) return;
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass) {
+        if (off[pass] < 0) continue;
+        f32x4 v = *(const f32x4 *)(a.part + off[pass]);
+#pragma unroll 4
+        for (int k = 1; k < a.splits; ++k) v += *(const f32x4 *)(a.part + (size_t)k * a.slab + off[pass]);
+        v = v * sc + sh;
+        if (a.res) v += *(const f32x4 *)(a.res + off[pass]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = apply_act(v[q], a.act);
+        *(f32x4 *)(a.out + off[pass]) = v;
+    }
 }
 
 template <int BM, int BN>
@@ -209,107 +325,177 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKArgs a) {
 #undef GDPSO_SSTORE
 #undef GDPSO_LOADFRAG
 
-    // Epilogue through LDS.  Accumulator register r of lane l is
-    // C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]; the tile is first laid out row-major
-    // in LDS (the K loop's last barrier has retired every operand read), then written with
-    // 16-byte stores: one wave instruction covers whole 256/512-byte row segments, and the
-    // residual is read the same way.
-    constexpr int LDC = BN + 4;
-    static_assert(BM * LDC <= 2 * (BM + BN) * LDA, "output tile must fit the operand buffers");
-    float *sC = lds;
+    conv_epilogue<BM, BN>(a, lds, 2 * (BM + BN) * LDA, acc, tid, m0, n0, ph, sp, nt, tile, off_y, off_x);
+}
+
+// ---------------------------------------------------------------------------------
+// Direct-to-LDS variant of the kernel above: the K-tiles of both operands travel
+// global -> LDS with global_load_lds_dwordx4 (no staging registers, no ds_write), STAGES
+// tiles deep, retired by counted vmcnt waits so that loads stay in flight across the one
+// barrier per K-tile.  A wave instruction writes 1 KiB of LDS linearly (lane l -> base +
+// 16 l), i.e. 8 rows of 32 floats: rows are unpadded, and bank conflicts of the 16-byte
+// fragment reads are avoided by an XOR swizzle of the 16-byte chunk index with
+// (row >> 1) & 7, applied to each lane's SOURCE column and again on the read.
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ void glds16(const float *src, float *lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
+}
+
+template <int BM, int BN, int STAGES>
+__global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvKArgs a) {
+    constexpr int WM = BM / 64, WN = BN / 64;
+    constexpr int PA = BM / 32, PB = BN / 32;  // wave instructions per K-tile, per operand
+    constexpr int LPT = PA + PB;               // loads one wave issues per K-tile
+    constexpr int STAGE = (BM + BN) * BK;      // floats per stage: A rows then B rows, 128-byte rows
+    constexpr int LDS_FLOATS = STAGES * STAGE > BM * (BN + 4) + 4 ? STAGES * STAGE : BM * (BN + 4) + 4;
+    static_assert(STAGES == 3 || STAGES == 4, "pipeline depth");
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    const int nt = gridDim.x, xq = nt >> 3, xr = nt & 7;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + slot;
+    const int tm = tile / a.tiles_n, tn = tile - tm * a.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int ph = blockIdx.z / a.splits, sp = blockIdx.z - ph * a.splits;
+    const int *tab = a.table + ph * PHASE_TABLE_INTS;
+    const int ntaps = tab[0], off_y = tab[1], off_x = tab[2];
+    const float *wt = a.wt + tab[3];
+    const int ktot = ntaps * a.cin;
+    const int kbeg = sp * a.ksplit;
+    const int kend = min(ktot, kbeg + a.ksplit);
+
+    // loader: this lane's row within a 32-row pass and its (swizzled) source column
+    const int r8 = lane >> 3;
+    const int lrow = 8 * wave + r8;
+    const int lcol = ((lane & 7) ^ ((lrow >> 1) & 7)) * 4;
+    int a_iy0[PA], a_ix0[PA], a_img[PA];
+    bool a_ok[PA];
+    const int hw = a.hm * a.wm;
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+        const int m = m0 + lrow + 32 * p;
+        a_ok[p] = m < a.M;
+        const int mm = a_ok[p] ? m : 0;
+        const int n = mm / hw, r = mm - n * hw;
+        const int my = r / a.wm, mx = r - my * a.wm;
+        a_iy0[p] = my * a.in_stride;
+        a_ix0[p] = mx * a.in_stride;
+        a_img[p] = n * a.hin * a.win;
+    }
+    const float *aptr[PA], *bptr[PB];
+    int tap = kbeg / a.cin, ci0 = kbeg - tap * a.cin;
+#define GDPSO_SET_TAP(CI)                                                                                       \
+    {                                                                                                           \
+        int packed_; /* scalar load: a vector load here would make the compiler drain the loads in flight */  \
+        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(packed_) : "s"(tab + 4 + tap) : "memory"); \
+        const int dy_ = (int)(short)(packed_ & 0xffff), dx_ = packed_ >> 16;                                    \
+        _Pragma("unroll") for (int p = 0; p < PA; ++p) {                                                        \
+            const int iy = a_iy0[p] + dy_, ix = a_ix0[p] + dx_;                                                 \
+            const bool ok = a_ok[p] && (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;        \
+            aptr[p] = ok ? a.in + (size_t)(a_img[p] + iy * a.win + ix) * a.cin + (CI) + lcol                    \
+                         : g_zero_page + (CI) + lcol;                                                           \
+        }                                                                                                       \
+    }
+    // one K-tile of both operands into stage ST (wave-uniform destinations, per-lane sources)
+#define GDPSO_ISSUE(ST)                                                                                         \
+    {                                                                                                           \
+        float *dst_ = lds + (ST) * STAGE + 8 * wave * BK;                                                       \
+        _Pragma("unroll") for (int p = 0; p < PA; ++p) {                                                        \
+            glds16(aptr[p], dst_ + 32 * p * BK);                                                                \
+            aptr[p] += BK;                                                                                      \
+        }                                                                                                       \
+        _Pragma("unroll") for (int p = 0; p < PB; ++p) {                                                        \
+            glds16(bptr[p], dst_ + BM * BK + 32 * p * BK);                                                      \
+            bptr[p] += BK;                                                                                      \
+        }                                                                                                       \
+        ci0 += BK;                                                                                              \
+        if (ci0 == a.cin) {                                                                                     \
+            ci0 = 0;                                                                                            \
+            if (++tap < ntaps) GDPSO_SET_TAP(0)                                                                 \
+        }                                                                                                       \
+    }
+
+    f32x16 acc[WM][WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < WN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                sC[(wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDC + wc * (BN / 2) + j * 32 + l31] = acc[i][j][r];
-    __syncthreads();
-    constexpr int C4 = BN / 4;     // float4 per tile row
-    constexpr int RPP = 256 / C4;  // tile rows per pass
-    constexpr int PASSES = BM / RPP;
-    const int c4 = tid % C4, r0 = tid / C4;
-    const int col = n0 + c4 * 4;
-    const bool direct = a.splits == 1;
-    const f32x4 sc = *(const f32x4 *)(a.scale + col), sh = *(const f32x4 *)(a.shift + col);
-    const bool remap = a.out_mul != 1 || a.hm != a.hout || a.wm != a.wout;
-    // element offset of this thread's 4 channels in each of its rows (-1: row past M)
-    long off[PASSES];
-#pragma unroll
-    for (int pass = 0; pass < PASSES; ++pass) {
-        const int m = m0 + pass * RPP + r0;
-        size_t pix = (size_t)m;
-        if (remap && m < a.M) {
-            const int n = m / hw, rr = m - n * hw;
-            const int my = rr / a.wm, mx = rr - my * a.wm;
-            pix = ((size_t)n * a.hout + my * a.out_mul + off_y) * a.wout + mx * a.out_mul + off_x;
-        }
-        off[pass] = m < a.M ? (long)(pix * a.cout + col) : -1;
-    }
-    if (direct) {
-#pragma unroll
-        for (int pass = 0; pass < PASSES; ++pass) {
-            if (off[pass] < 0) continue;
-            f32x4 v = *(const f32x4 *)&sC[(pass * RPP + r0) * LDC + c4 * 4];
-            v = v * sc + sh;
-            if (a.res) v += *(const f32x4 *)(a.res + off[pass]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = apply_act(v[q], a.act);
-            *(f32x4 *)(a.out + off[pass]) = v;
-        }
-        return;
-    }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // Split-K: every split writes its partial tile to its slab; the workgroup that arrives
-    // last at the tile's counter sums the slabs in split order (so the result does not
-    // depend on who is last) and applies the epilogue.  Hand-off: write-through (sc1) 16-byte
-    // slab stores, which need no L2 write-back; every wave drains its stores; workgroup
-    // barrier; one lane adds to the counter.  The last arriver takes one agent-scope acquire
-    // (drops this CU's stale L1 lines) before anyone loads.
-    float *slab = a.part + (size_t)sp * a.slab;
-    if (a.counters == nullptr) {  // reduction by the separate kernel
+    const int T = kbeg < kend ? (kend - kbeg) / BK : 0;
+    if (T > 0) {
+        GDPSO_SET_TAP(ci0)
 #pragma unroll
-        for (int pass = 0; pass < PASSES; ++pass)
-            if (off[pass] >= 0) *(f32x4 *)(slab + off[pass]) = *(const f32x4 *)&sC[(pass * RPP + r0) * LDC + c4 * 4];
-        return;
-    }
-    {
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(slab, 0, (int)(a.slab * 4), 0x00020000);
+        for (int p = 0; p < PB; ++p) bptr[p] = wt + (size_t)(n0 + lrow + 32 * p) * ktot + kbeg + lcol;
 #pragma unroll
-        for (int pass = 0; pass < PASSES; ++pass)
-            if (off[pass] >= 0)
-                __builtin_amdgcn_raw_buffer_store_b128(
-                    __builtin_bit_cast(u32x4, *(const f32x4 *)&sC[(pass * RPP + r0) * LDC + c4 * 4]), rsrc,
-                    (int)(off[pass] * 4), 0, 16 /* sc1 */);
+        for (int t = 0; t < STAGES - 1; ++t)
+            if (t < T) GDPSO_ISSUE(t)
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int *s_last = (int *)&lds[2 * (BM + BN) * LDA - 4];  // past the output tile
-    if (tid == 0) {
-        int *cnt = a.counters + ph * nt + tile;
-        const int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = ticket == a.splits - 1;
-        if (last) {
-            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // fragment read offsets: logical chunk 2g + half of this lane's row, swizzled like the loads
+    int foff[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) foff[g] = ((2 * g + half) ^ ((l31 >> 1) & 7)) * 4;
+    const int a_row = (wr * (BM / 2) + l31) * BK, b_row = BM * BK + (wc * (BN / 2) + l31) * BK;
+    int stage = 0;
+    for (int t = 0; t < T; ++t) {
+        // retire tile t: everything but the loads of the (at most STAGES - 2) tiles behind it
+        const int behind = min(STAGES - 2, T - 1 - t);
+        if (behind >= 2)
+            wait_vmcnt<2 * LPT>();
+        else if (behind == 1)
+            wait_vmcnt<LPT>();
+        else
+            wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();  // tile t has landed for every wave; tile t-1 is no longer being read
+        if (t + STAGES - 1 < T) {
+            const int st = stage == 0 ? STAGES - 1 : stage - 1;  // the stage tile t-1 used
+            GDPSO_ISSUE(st)
         }
-        *s_last = last;
+        const float *pa = lds + stage * STAGE + a_row;
+        const float *pb = lds + stage * STAGE + b_row;
+        f32x4 av[2][WM], bv[2][WN];
+#define GDPSO_LOADFRAG(SET, G)                                                                                  \
+    {                                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < WM; ++i) av[SET][i] = *(const f32x4 *)(pa + i * 32 * BK + foff[G]); \
+        _Pragma("unroll") for (int j = 0; j < WN; ++j) bv[SET][j] = *(const f32x4 *)(pb + j * 32 * BK + foff[G]); \
     }
-    __syncthreads();
-    if (!*s_last) return;
+        GDPSO_LOADFRAG(0, 0)
 #pragma unroll
-    for (int pass = 0; pass < PASSES; ++pass) {
-        if (off[pass] < 0) continue;
-        f32x4 v = *(const f32x4 *)(a.part + off[pass]);
-#pragma unroll 4
-        for (int k = 1; k < a.splits; ++k) v += *(const f32x4 *)(a.part + (size_t)k * a.slab + off[pass]);
-        v = v * sc + sh;
-        if (a.res) v += *(const f32x4 *)(a.res + off[pass]);
+        for (int g = 0; g < 4; ++g) {
+            if (g < 3) GDPSO_LOADFRAG((g + 1) & 1, g + 1)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = apply_act(v[q], a.act);
-        *(f32x4 *)(a.out + off[pass]) = v;
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1][i][s], bv[g & 1][j][s], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, WM + WN, 0);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x100, WM + WN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * WM * WN, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * WM * WN, 0);
+        stage = stage + 1 == STAGES ? 0 : stage + 1;
     }
+#undef GDPSO_SET_TAP
+#undef GDPSO_ISSUE
+#undef GDPSO_LOADFRAG
+    __syncthreads();  // every wave is done reading operands before the tile goes through LDS
+    conv_epilogue<BM, BN>(a, lds, LDS_FLOATS, acc, tid, m0, n0, ph, sp, nt, tile, off_y, off_x);
 }
 
 // Sums the split-K slabs and applies the epilogue.  One float4 (4 channels) per thread.
@@ -347,6 +533,12 @@ struct ConvTiming {
     double flops = 0.0;
 } g_timing;
 }  // namespace
+
+// Development switch between the register-staged kernel and the direct-to-LDS one.
+static bool g_use_dma = [] {
+    const char *e = getenv("GDPSO_CONV_DMA");
+    return e ? e[0] != '0' : true;
+}();
 
 static long max_ktot(const ConvLayer &L) {
     long k = 0;
@@ -417,10 +609,17 @@ int launch_conv(const ConvLayer &L, hipStream_t stream, int n_images, const floa
     dim3 grid(tiles_m * a.tiles_n, 1, L.nphase * L.splits);
     const bool timed = g_timing.on && g_timing.used + 2 <= g_timing.events.size();
     if (timed) GDPSO_HIP(hipEventRecord(g_timing.events[g_timing.used], stream));
-    if (L.tile == 128)
-        hipLaunchKernelGGL((conv_gemm_kernel<128, 128>), grid, dim3(256), 0, stream, a);
-    else
-        hipLaunchKernelGGL((conv_gemm_kernel<64, 64>), grid, dim3(256), 0, stream, a);
+    if (g_use_dma) {
+        if (L.tile == 128)
+            hipLaunchKernelGGL((conv_gemm_dma_kernel<128, 128, 3>), grid, dim3(256), 0, stream, a);
+        else
+            hipLaunchKernelGGL((conv_gemm_dma_kernel<64, 64, 4>), grid, dim3(256), 0, stream, a);
+    } else {
+        if (L.tile == 128)
+            hipLaunchKernelGGL((conv_gemm_kernel<128, 128>), grid, dim3(256), 0, stream, a);
+        else
+            hipLaunchKernelGGL((conv_gemm_kernel<64, 64>), grid, dim3(256), 0, stream, a);
+    }
     if (timed) {
         GDPSO_HIP(hipEventRecord(g_timing.events[g_timing.used + 1], stream));
         g_timing.used += 2;

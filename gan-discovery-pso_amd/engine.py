@@ -420,17 +420,28 @@ class TorchComm:
         import torch.distributed as dist
         self.dist, self.group = dist, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        # gloo handles device tensors through host staging outside stream order (rehearsal
+        # path only): drain the device first.  RCCL collectives are stream-ordered.
+        self.drain_first = dist.get_backend(group) == "gloo"
+
+    def _drain(self, t):
+        if self.drain_first and t.is_cuda:
+            torch.cuda.synchronize(t.device)
 
     def all_gather(self, out: torch.Tensor, inp: torch.Tensor):
         # out [W, d+2] is the swarm's candidate table; inp is this rank's row of it
+        self._drain(out)
         self.dist.all_gather_into_tensor(out.view(-1), inp.clone().view(-1), group=self.group)
+        self._drain(out)
 
     def gather_positions(self, pos: torch.Tensor, n_global: int) -> torch.Tensor:
         n_max = -(-n_global // self.world)
         pad = torch.zeros(n_max, pos.shape[1], dtype=pos.dtype, device=pos.device)
         pad[:pos.shape[0]] = pos
         allp = torch.empty(self.world * n_max, pos.shape[1], dtype=pos.dtype, device=pos.device)
+        self._drain(pad)
         self.dist.all_gather_into_tensor(allp.view(-1), pad.view(-1), group=self.group)
+        self._drain(pad)
         if n_global == self.world * n_max:
             return allp
         rows = []
