@@ -17,6 +17,8 @@
 // BK = 32, two LDS buffers, register prefetch of the next K-tile, one barrier per K-tile.
 // Small-M layers (late ResNet stages at 1x1..4x4) use 64x64 tiles plus split-K over
 // blockIdx.z with fp32 partial slabs and a fused reduce+epilogue kernel.
+#include <hip/hip_ext.h>
+
 #include <cstdlib>
 
 #include "common.h"
@@ -534,10 +536,18 @@ struct ConvTiming {
 } g_timing;
 }  // namespace
 
-// Development switch between the register-staged kernel and the direct-to-LDS one.
+// Development switches (A/B measurements on one device).  Measured at 512 images on MI355X:
+// the register-staged kernel with the separate split-K reduce kernel is 1-3 % faster end to
+// end than the direct-to-LDS kernel and than the in-kernel (last-arriver) reduction, which
+// only pay on much longer K loops / larger grids (103 vs 100 TFLOP/s at 8192 x 2048 x 4096).
 static bool g_use_dma = [] {
     const char *e = getenv("GDPSO_CONV_DMA");
-    return e ? e[0] != '0' : true;
+    return e ? e[0] != '0' : false;
+}();
+
+static int g_fused_max_splits = [] {
+    const char *e = getenv("GDPSO_SPLITK_FUSED_MAX");
+    return e ? atoi(e) : 0;
 }();
 
 static long max_ktot(const ConvLayer &L) {
@@ -587,9 +597,8 @@ int launch_conv(const ConvLayer &L, hipStream_t stream, int n_images, const floa
     ConvKArgs a;
     a.in = in; a.wt = L.wt; a.scale = L.scale; a.shift = L.shift; a.res = res; a.out = out;
     const int tiles_total = ceil_div((long)n_images * L.hm * L.wm, L.tile) * (L.cout / L.tile) * L.nphase;
-    // measured: the in-kernel (last-arriver) reduction beats the separate reduce kernel up to
-    // 4 splits; beyond that the last arriver's serial slab reads cost more than a launch
-    const bool fused_reduce = L.splits > 1 && L.splits <= 4 && (size_t)tiles_total * sizeof(int) <= SPLITK_COUNTER_BYTES;
+    // in-kernel (last-arriver) reduction up to GDPSO_SPLITK_FUSED_MAX splits (default: off)
+    const bool fused_reduce = L.splits > 1 && L.splits <= g_fused_max_splits && (size_t)tiles_total * sizeof(int) <= SPLITK_COUNTER_BYTES;
     a.part = L.splits > 1 ? splitk_ws + SPLITK_COUNTER_BYTES / sizeof(float) : nullptr;
     a.counters = fused_reduce ? (int *)splitk_ws : nullptr;
     a.table = L.table;
@@ -607,21 +616,31 @@ int launch_conv(const ConvLayer &L, hipStream_t stream, int n_images, const floa
     if (a.slab * 4 >= (1L << 31)) return fail(GDPSO_ERR_ARG, "conv: output larger than 2 GiB");
     const int tiles_m = ceil_div(a.M, L.tile);
     dim3 grid(tiles_m * a.tiles_n, 1, L.nphase * L.splits);
+    // With timing on, the kernel's own begin/end timestamps are attached to two events by the
+    // launch itself (no extra markers on the stream, so nothing but the kernel is timed).
     const bool timed = g_timing.on && g_timing.used + 2 <= g_timing.events.size();
-    if (timed) GDPSO_HIP(hipEventRecord(g_timing.events[g_timing.used], stream));
+    hipEvent_t e0 = timed ? g_timing.events[g_timing.used] : nullptr;
+    hipEvent_t e1 = timed ? g_timing.events[g_timing.used + 1] : nullptr;
+#define GDPSO_LAUNCH(KERNEL)                                                                 \
+    if (timed)                                                                               \
+        hipExtLaunchKernelGGL((KERNEL), grid, dim3(256), 0, stream, e0, e1, 0, a);           \
+    else                                                                                     \
+        hipLaunchKernelGGL((KERNEL), grid, dim3(256), 0, stream, a);
     if (g_use_dma) {
-        if (L.tile == 128)
-            hipLaunchKernelGGL((conv_gemm_dma_kernel<128, 128, 3>), grid, dim3(256), 0, stream, a);
-        else
-            hipLaunchKernelGGL((conv_gemm_dma_kernel<64, 64, 4>), grid, dim3(256), 0, stream, a);
+        if (L.tile == 128) {
+            GDPSO_LAUNCH((conv_gemm_dma_kernel<128, 128, 3>))
+        } else {
+            GDPSO_LAUNCH((conv_gemm_dma_kernel<64, 64, 4>))
+        }
     } else {
-        if (L.tile == 128)
-            hipLaunchKernelGGL((conv_gemm_kernel<128, 128>), grid, dim3(256), 0, stream, a);
-        else
-            hipLaunchKernelGGL((conv_gemm_kernel<64, 64>), grid, dim3(256), 0, stream, a);
+        if (L.tile == 128) {
+            GDPSO_LAUNCH((conv_gemm_kernel<128, 128>))
+        } else {
+            GDPSO_LAUNCH((conv_gemm_kernel<64, 64>))
+        }
     }
+#undef GDPSO_LAUNCH
     if (timed) {
-        GDPSO_HIP(hipEventRecord(g_timing.events[g_timing.used + 1], stream));
         g_timing.used += 2;
         g_timing.flops += L.flops_nominal * n_images;
     }

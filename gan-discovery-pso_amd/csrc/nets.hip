@@ -34,19 +34,19 @@ __global__ __launch_bounds__(256) void latent_prep_kernel(const void *__restrict
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 template <bool STAGED>
-__global__ __launch_bounds__(256) void gen_last_kernel(const float *__restrict__ a2, const float *__restrict__ w5,
+__global__ __launch_bounds__(512) void gen_last_kernel(const float *__restrict__ a2, const float *__restrict__ w5,
                                                        float bias, int hin, int cin, float *__restrict__ img,
                                                        float *__restrict__ img01, const float *__restrict__ target,
                                                        float *__restrict__ mse) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int side = 2 * hin, npix = side * side, nin = hin * hin;
     float *s_img = smem;            // [npix]
-    float *s_red = s_img + npix;    // [16]: min, max, squared error of the 4 waves
-    float *s_a2 = s_red + 16;       // [nin][cin] when STAGED
+    float *s_red = s_img + npix;    // [3][8]: min, max, squared error of the 8 waves
+    float *s_a2 = s_red + 32;       // [nin][cin] when STAGED
     const int tid = threadIdx.x, n = blockIdx.x;
     const float *src = a2 + (size_t)n * nin * cin;
     if (STAGED) {
-        for (int i = tid * 4; i < nin * cin; i += 1024) *(f32x4 *)&s_a2[i] = *(const f32x4 *)&src[i];
+        for (int i = tid * 4; i < nin * cin; i += 2048) *(f32x4 *)&s_a2[i] = *(const f32x4 *)&src[i];
         __syncthreads();
     }
     const float *act = STAGED ? s_a2 : src;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void gen_last_kernel(const float *__restrict__
                 w10 = *(const f32x4 *)&w5[(ky1 * 4 + kx0) * cin + c];
                 w11 = *(const f32x4 *)&w5[(ky1 * 4 + kx1) * cin + c];
             }
-            for (int q0 = 0; q0 < nin; q0 += 16) {
+            for (int q0 = 0; q0 < nin; q0 += 32) {
                 const int q = q0 + grp;
                 float acc = 0.f;
                 if (q < nin && cok) {
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void gen_last_kernel(const float *__restrict__
     float mn = INFINITY, mx = -INFINITY, se = 0.f;
     float *dst = img ? img + (size_t)n * npix : nullptr;
     const float *tg = target ? target + (size_t)n * npix : nullptr;
-    for (int i = tid; i < npix; i += 256) {
+    for (int i = tid; i < npix; i += 512) {
         const float v = tanhf(s_img[i] + bias);
         s_img[i] = v;
         mn = fminf(mn, v);
@@ -122,27 +122,34 @@ __global__ __launch_bounds__(256) void gen_last_kernel(const float *__restrict__
     }
     if ((tid & 63) == 0) {
         s_red[tid >> 6] = mn;
-        s_red[4 + (tid >> 6)] = mx;
-        s_red[8 + (tid >> 6)] = se;
+        s_red[8 + (tid >> 6)] = mx;
+        s_red[16 + (tid >> 6)] = se;
     }
     __syncthreads();
-    mn = fminf(fminf(s_red[0], s_red[1]), fminf(s_red[2], s_red[3]));
-    mx = fmaxf(fmaxf(s_red[4], s_red[5]), fmaxf(s_red[6], s_red[7]));
+    mn = s_red[0];
+    mx = s_red[8];
+    se = s_red[16];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        mn = fminf(mn, s_red[k]);
+        mx = fmaxf(mx, s_red[8 + k]);
+        se += s_red[16 + k];
+    }
     const float range = mx - mn;
     float *d01 = img01 + (size_t)n * npix;
-    for (int i = tid; i < npix; i += 256) d01[i] = (s_img[i] - mn) / range;  // each thread rescales the pixels it wrote
-    if (mse && tid == 0) mse[n] = ((s_red[8] + s_red[9]) + (s_red[10] + s_red[11])) / (float)npix;
+    for (int i = tid; i < npix; i += 512) d01[i] = (s_img[i] - mn) / range;  // each thread rescales the pixels it wrote
+    if (mse && tid == 0) mse[n] = se / (float)npix;
 }
 
 // ---------------------------------------------------------------------------------
 // Assessor stem, fused: Conv2d(1 -> 64, k7, s2, p3, no bias) + BatchNorm + ReLU +
 // MaxPool2d(3, s2, p1) (reference src/pso/util_cnn.py:85-88, 103-106).  NHWC output.
 // Grid (image, band of pooled rows).  Lane = output channel (its 49 weights live in
-// registers); the four waves take PAIRS of horizontally adjacent conv pixels round-robin:
+// registers); the eight waves take PAIRS of horizontally adjacent conv pixels round-robin:
 // the two 7-wide windows of a pair span 9 input pixels, read from the zero-padded image
 // in LDS as three wave-wide broadcast 16-byte reads per kernel row (row stride and window
 // start are multiples of 4 floats).  Conv rows of the band stay in LDS for the pooling.
-__global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ img01, const float *__restrict__ w,
+__global__ __launch_bounds__(512) void stem_kernel(const float *__restrict__ img01, const float *__restrict__ w,
                                                    const float *__restrict__ scale, const float *__restrict__ shift,
                                                    int side, int ho, int hp, int band, int ps, float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -154,7 +161,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ img
     const int pr1 = min(hp, pr0 + band);
     const int cr0 = 2 * pr0 - 1, cr1 = 2 * (pr1 - 1) + 1;  // conv rows needed (may stick out)
     const float *src = img01 + (size_t)n * side * side;
-    for (int i = tid; i < prows * ps; i += 256) {
+    for (int i = tid; i < prows * ps; i += 512) {
         const int y = i / ps - 3, x = i % ps - 3;
         s_img[i] = ((unsigned)y < (unsigned)side && (unsigned)x < (unsigned)side) ? src[y * side + x] : 0.f;
     }
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ img
     const float sc = scale[c], sh = shift[c];
     __syncthreads();
     const int rows = cr1 - cr0 + 1, pairs = (ho + 1) >> 1;
-    for (int p = q; p < rows * pairs; p += 4) {
+    for (int p = q; p < rows * pairs; p += 8) {
         const int r = p / pairs, cx = 2 * (p - r * pairs), cy = cr0 + r;
         float v0 = 0.f, v1 = 0.f;
         if ((unsigned)cy < (unsigned)ho) {
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ img
         if (cx + 1 < ho) s_conv[(r * ho + cx + 1) * 64 + c] = v1;
     }
     __syncthreads();
-    for (int p = q; p < (pr1 - pr0) * hp; p += 4) {
+    for (int p = q; p < (pr1 - pr0) * hp; p += 8) {
         const int pr = pr0 + p / hp, pc = p % hp;
         float m = -INFINITY;
 #pragma unroll
@@ -441,12 +448,12 @@ extern "C" int gdpso_generator_forward(const gdpso_generator *g, void *stream_, 
     if ((rc = launch_conv(l1, stream, n, zpad, nullptr, a1, sk))) return rc;
     if ((rc = launch_conv(l2, stream, n, a1, nullptr, a2, sk))) return rc;
     const int hin = 2 * g->k1;
-    const size_t base = ((size_t)g->side * g->side + 16) * sizeof(float);
+    const size_t base = ((size_t)g->side * g->side + 32) * sizeof(float);
     const size_t staged = base + (size_t)hin * hin * g->features * sizeof(float);
     if (staged <= 64 * 1024)
-        hipLaunchKernelGGL(gen_last_kernel<true>, dim3(n), dim3(256), staged, stream, a2, g->w5, g->b5, hin, g->features, img, img01, target, mse);
+        hipLaunchKernelGGL(gen_last_kernel<true>, dim3(n), dim3(512), staged, stream, a2, g->w5, g->b5, hin, g->features, img, img01, target, mse);
     else
-        hipLaunchKernelGGL(gen_last_kernel<false>, dim3(n), dim3(256), base, stream, a2, g->w5, g->b5, hin, g->features, img, img01, target, mse);
+        hipLaunchKernelGGL(gen_last_kernel<false>, dim3(n), dim3(512), base, stream, a2, g->w5, g->b5, hin, g->features, img, img01, target, mse);
     GDPSO_HIP(hipGetLastError());
     return GDPSO_OK;
 }
@@ -610,7 +617,7 @@ extern "C" int gdpso_assessor_forward(const gdpso_assessor *a, void *stream_, in
         const int rows = 2 * a->stem_band + 1;
         const size_t smem = ((size_t)(a->side + 6) * a->stem_ps + (size_t)rows * a->ho * 64) * sizeof(float);
         dim3 grid(n, ceil_div(a->hp, a->stem_band));
-        hipLaunchKernelGGL(stem_kernel, grid, dim3(256), smem, stream, img01, a->stem_w, a->stem_scale, a->stem_shift, a->side,
+        hipLaunchKernelGGL(stem_kernel, grid, dim3(512), smem, stream, img01, a->stem_w, a->stem_scale, a->stem_shift, a->side,
                            a->ho, a->hp, a->stem_band, a->stem_ps, x);
     }
     int rc;
