@@ -174,9 +174,22 @@ def main():
         ms, launches, flops = C.c_double(), C.c_int(), C.c_double()
         lib.check(L.gdpso_conv_timing_end(C.byref(ms), C.byref(launches), C.byref(flops)))
         achieved = flops.value / (ms.value * 1e-3) / 1e12
+        alg_bytes = L.gdpso_conv_timing_bytes() / launches.value
+        # HBM bytes per launch from the committed PMC passes of this same command (counters cannot be
+        # read from inside the process); null when the summary is absent or was taken at another size
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")) as f:
+                pm = json.load(f)
+            if p == 512 and z_dim == 10:
+                traffic = pm["kernels"]["gdpso::conv_gemm_kernel<64, 64>"]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         roofline = {"bound": "mfma", "kernel": "conv_gemm_kernel (fp32-input MFMA implicit GEMM)",
                     "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_hbm_traffic.json)",
+                    "algorithmic_bytes_per_launch": round(alg_bytes),
                     "launches_per_step": launches.value // k, "avg_launch_us": round(1e3 * ms.value / launches.value, 3),
                     "conv_ms_per_step": round(ms.value / k, 4),
                     "algorithmic_gflop_per_step": round(flops.value / k / 1e9, 3)}

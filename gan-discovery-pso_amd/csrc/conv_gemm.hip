@@ -533,6 +533,7 @@ struct ConvTiming {
     std::vector<hipEvent_t> events;
     size_t used = 0;
     double flops = 0.0;
+    double bytes = 0.0;  // input + weights + output (+ residual), each counted once per launch
 } g_timing;
 }  // namespace
 
@@ -643,6 +644,9 @@ int launch_conv(const ConvLayer &L, hipStream_t stream, int n_images, const floa
     if (timed) {
         g_timing.used += 2;
         g_timing.flops += L.flops_nominal * n_images;
+        double wbytes = 0.0;
+        for (int p = 0; p < L.nphase; ++p) wbytes += (double)L.phase[p].ntaps * L.cin * L.cout;
+        g_timing.bytes += 4.0 * ((double)n_images * L.hin * L.win * L.cin + wbytes + (double)a.slab * (res ? 2 : 1));
     }
     if (L.splits > 1 && !fused_reduce) {
         const long quads = a.slab / 4;
@@ -665,6 +669,7 @@ extern "C" int gdpso_conv_timing_begin(int max_launches) {
     }
     g_timing.used = 0;
     g_timing.flops = 0.0;
+    g_timing.bytes = 0.0;
     g_timing.on = true;
     return GDPSO_OK;
 }
@@ -684,6 +689,8 @@ extern "C" int gdpso_conv_timing_end(double *total_ms, int *launches, double *fl
     if (flops) *flops = g_timing.flops;
     return GDPSO_OK;
 }
+
+extern "C" double gdpso_conv_timing_bytes(void) { return gdpso::g_timing.bytes; }
 
 // Times one convolution layer in isolation (development / tuning aid): random weights and
 // inputs, `reps` back-to-back launches bracketed by HIP events.  tile = 0 / splits = 0 keep

@@ -227,6 +227,9 @@ int gdpso_swarm_iterate(const gdpso_swarm *s, const gdpso_generator *g, const gd
  * (2 per multiply-accumulate, padding taps included).  Not thread-safe. */
 int gdpso_conv_timing_begin(int max_launches);
 int gdpso_conv_timing_end(double *total_ms, int *launches, double *flops);
+/* Algorithmic bytes of the launches timed since the last gdpso_conv_timing_begin: input, weights,
+ * output and residual of every launch, each counted once. */
+double gdpso_conv_timing_bytes(void);
 
 /* No counterpart in the reference: times one ksize x ksize convolution layer in isolation
  * on random data (allocates and frees its own buffers; a development / tuning aid).
