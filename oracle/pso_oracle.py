@@ -192,7 +192,7 @@ def mean_pairwise_distance(pos: np.ndarray) -> float:
 
 def run_swarm(fitness, pos, vel, n_iterations, w_inertia, w_cogn, w_soci, *, tolerance=1e-4,
               schedule_inertia=False, early_stopping=True, rand=None, rng=np.random,
-              batch: int = 1, record=True, diagnostics=True):
+              batch: int = 1, record=True, diagnostics=True, f32_first_move=False):
     """The optimisation loop of reference util_pso.py:167-193, on SoA arrays.
 
     ``fitness(pos[B,D], first) -> float32[B]``.  ``batch=1`` evaluates one particle per
@@ -200,6 +200,12 @@ def run_swarm(fitness, pos, vel, n_iterations, w_inertia, w_cogn, w_soci, *, tol
     networks at once.  ``rand`` [T,N,2] supplies (r1, r2) per particle per iteration; when
     None they are drawn from ``rng`` in the reference's order (util_pso.py:45,47: r1 then
     r2, particle by particle).
+
+    ``f32_first_move`` restates the inverter variant (util_pso.py:93-112): positions come
+    out of the encoder as float32 arrays, so in the first move ``g_best_pos - pos`` and
+    ``p_best_pos - pos`` are float32 differences multiplied by a python float (numpy keeps
+    float32 for that), and only the sum with the float64 inertia term promotes to float64.
+    From the second move on every position is float64.
 
     Returns a dict with the quantities the reference exposes: ``g_best_val`` (list that
     grows only on improvement, :143-149), ``g_best_val_dummy`` (one entry per iteration,
@@ -250,8 +256,13 @@ def run_swarm(fitness, pos, vel, n_iterations, w_inertia, w_cogn, w_soci, *, tol
         r = rand[i - 1] if rand is not None else rng.random((n, 2))
         r1, r2 = r[:, 0:1], r[:, 1:2]
         inertia = w * vel
-        best_cogn = (w_cogn * r1) * (g_best_pos[None, :] - pos)
-        best_soci = (w_soci * r2) * (pbest_pos - pos)
+        if f32_first_move and i == 1:
+            p32 = pos.astype(np.float32)
+            best_cogn = ((w_cogn * r1).astype(np.float32) * (g_best_pos.astype(np.float32)[None, :] - p32)).astype(np.float64)
+            best_soci = ((w_soci * r2).astype(np.float32) * (pbest_pos.astype(np.float32) - p32)).astype(np.float64)
+        else:
+            best_cogn = (w_cogn * r1) * (g_best_pos[None, :] - pos)
+            best_soci = (w_soci * r2) * (pbest_pos - pos)
         vel = inertia + best_soci + best_cogn
         pos = pos + vel
         if diagnostics:

@@ -83,6 +83,41 @@ def test_swarm_trajectory(oracle, synth, name):
     assert abs(out["w_inertia"] - float(g["w_inertia_final"])) < 1e-15
 
 
+@pytest.mark.parametrize("name", ["inverter_in_n8_t5", "inverter_out_n8_t5"])
+def test_inverter_variant(oracle, synth, name):
+    """Encoder-seeded float32 positions, MSE-augmented fitness with eps counted twice and the
+    float32 first move (reference util_pso.py:93-112, util_discovery.py:84-101)."""
+    g = load_golden(name)
+    gsd, csd = _weights(synth, g)
+    zd, n = int(g["z_dim"]), int(g["n"])
+    esd = synth.encoder_state(zd, 1, 64, seed=int(g["enc_seed"]))
+    assert synth.checksum(esd) == str(g["enc_ck"])
+    targets = torch.from_numpy(g["targets"])
+    with torch.no_grad():
+        lat = oracle.encoder_forward(synth.to_torch(esd), targets).numpy()
+    np.testing.assert_allclose(lat, g["encoder_latents"], rtol=1e-4, atol=1e-4)
+    # the swarm starts from the reference's own latents so that one encoder ulp cannot move the run
+    pos0 = g["encoder_latents"].reshape(n, zd)
+    np.testing.assert_array_equal(pos0.astype(np.float64), g["pos"][0])
+    np.random.seed(int(g["np_seed"]))
+    vel0 = oracle.init_velocities(n, zd)
+    np.testing.assert_array_equal(vel0, g["vel"][0])
+    fit = oracle.Fitness(gsd, csd, 1, str(g["mode"]), targets=targets)
+    w = g["w"]
+    out = oracle.run_swarm(fit, pos0, vel0, int(g["t"]), w[0], w[1], w[2], tolerance=float(g["tolerance"]),
+                           schedule_inertia=False, early_stopping=False, batch=1, f32_first_move=True)
+    np.testing.assert_allclose(np.stack(out["fitness"]), g["fitness"], atol=TOL)
+    np.testing.assert_allclose(np.stack(out["pos"]), g["pos"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(np.stack(out["vel"]), g["vel"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(np.array(out["g_best_val_dummy"], np.float32), g["g_best_val_dummy"], atol=TOL)
+    # the swarm arithmetic alone, fed the reference's fitness values and draws, is bit-exact
+    calls = iter(g["fitness"])
+    rep = oracle.run_swarm(lambda p, s: next(calls), g["pos"][0], g["vel"][0], int(g["t"]), w[0], w[1], w[2],
+                           early_stopping=False, rand=g["rand"], batch=n, f32_first_move=True)
+    np.testing.assert_array_equal(np.stack(rep["pos"]), g["pos"])
+    np.testing.assert_array_equal(np.stack(rep["vel"]), g["vel"])
+
+
 def test_rand_replay_matches_draw_order(oracle):
     """r1/r2 stored in the fixtures are the reference's own draws: feeding them back
     explicitly gives the same trajectory as drawing from the seeded global stream."""
