@@ -670,7 +670,7 @@ EncLayout enc_layout(const gdpso_encoder *e, int n, ConvLayer &c2, ConvLayer &c3
 
 extern "C" int gdpso_encoder_create(gdpso_encoder **out, int enc_dim, int features_e, const float *const *t, int n_tensors) {
     GDPSO_REQUIRE(out && t, "encoder_create: null argument");
-    GDPSO_REQUIRE(n_tensors == 6, "encoder_create: expected 6 tensors");
+    GDPSO_REQUIRE(n_tensors == 6 || n_tensors == 10, "encoder_create: expected 6 tensors (or 10 with BatchNorm)");
     GDPSO_REQUIRE(enc_dim > 0 && features_e >= 32 && features_e % 32 == 0, "encoder_create: features_e must be a multiple of 32");
     auto e = new gdpso_encoder();
     e->enc_dim = enc_dim;
@@ -685,8 +685,12 @@ extern "C" int gdpso_encoder_create(gdpso_encoder **out, int enc_dim, int featur
     if ((rc = e->arena.upload(w1, &e->w1)) || (rc = e->arena.upload(b1, &e->b1))) { delete e; return rc; }
     std::vector<float> packed, ones, bias;
     make_conv(e->c2, t[2], c2, c1, 4, 4, 2, 1, 14, 14, ACT_LEAKY02, packed);
-    ones.assign(c2, 1.f);
-    bias.assign(t[3], t[3] + c2);
+    if (n_tensors == 10) {
+        fold_bn(c2, t[3], t[6], t[7], t[8], t[9], ones, bias);  // eval-mode BatchNorm after the second convolution
+    } else {
+        ones.assign(c2, 1.f);
+        bias.assign(t[3], t[3] + c2);
+    }
     if ((rc = upload_conv(e->arena, e->c2, packed, ones, bias))) { delete e; return rc; }
     make_conv(e->c3, t[4], enc_dim, c2, 7, 7, 2, 0, 7, 7, ACT_NONE, packed, 0, e->out_pad);
     ones.assign(e->out_pad, 1.f);

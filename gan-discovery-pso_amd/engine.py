@@ -33,12 +33,15 @@ def _np(sd, key):
 
 
 # ------------------------------------------------------------------ state_dict readers
-def generator_tensors(sd):
+def generator_tensors(sd, prefix="gen"):
     """The 14 arrays gdpso_generator_create wants, from the generator's state_dict keys
-    (reference src/utils/util_dcgan.py:133-139: gen.0.0, gen.0.1, gen.1.0, gen.1.1, gen.2)."""
-    keys = ["gen.0.0.weight", "gen.0.0.bias"] + [f"gen.0.1.{f}" for f in BN_FIELDS]
-    keys += ["gen.1.0.weight", "gen.1.0.bias"] + [f"gen.1.1.{f}" for f in BN_FIELDS]
-    keys += ["gen.2.weight", "gen.2.bias"]
+    (reference src/utils/util_dcgan.py:133-139: gen.0.0, gen.0.1, gen.1.0, gen.1.1, gen.2;
+    ``prefix="decoder"`` reads the same stack out of a VectorQuantizedVAE_GAN,
+    src/inverter/utils_vq_vae/util_model.py:283-289)."""
+    g = prefix
+    keys = [f"{g}.0.0.weight", f"{g}.0.0.bias"] + [f"{g}.0.1.{f}" for f in BN_FIELDS]
+    keys += [f"{g}.1.0.weight", f"{g}.1.0.bias"] + [f"{g}.1.1.{f}" for f in BN_FIELDS]
+    keys += [f"{g}.2.weight", f"{g}.2.bias"]
     t = [_np(sd, k) for k in keys]
     z_dim, c1, k, _ = t[0].shape
     if t[12].shape[1] != 1:
@@ -69,9 +72,14 @@ def resnet_tensors(sd):
     return t, dict(depths=tuple(depths), n_class=int(t[-1].shape[0]))
 
 
-def encoder_tensors(sd):
-    """reference src/inverter/utils_ae/util_inverter.py:168-174: enc.0, enc.2.0, enc.3."""
-    keys = ["enc.0.weight", "enc.0.bias", "enc.2.0.weight", "enc.2.0.bias", "enc.3.weight", "enc.3.bias"]
+def encoder_tensors(sd, prefix="enc"):
+    """reference src/inverter/utils_ae/util_inverter.py:168-174: enc.0, enc.2.0, enc.3.
+    ``prefix="encoder"`` reads the encoder of a VectorQuantizedVAE_GAN, which has a
+    BatchNorm after the second convolution (src/inverter/utils_vq_vae/util_model.py:273-279)."""
+    e = prefix
+    keys = [f"{e}.0.weight", f"{e}.0.bias", f"{e}.2.0.weight", f"{e}.2.0.bias", f"{e}.3.weight", f"{e}.3.bias"]
+    if f"{e}.2.1.weight" in sd:
+        keys += [f"{e}.2.1.{f}" for f in BN_FIELDS]
     t = [_np(sd, k) for k in keys]
     return t, dict(enc_dim=int(t[4].shape[0]), features_e=int(t[0].shape[0]))
 
@@ -107,10 +115,10 @@ class PackedGenerator(_Handle):
     """Generator weights repacked on the device (gdpso_generator_create)."""
     _destroy = "gdpso_generator_destroy"
 
-    def __init__(self, model, device):
+    def __init__(self, model, device, prefix="gen"):
         super().__init__()
         self.device = _device_guard(device)
-        tensors, self.meta = generator_tensors(_state_dict_of(model))
+        tensors, self.meta = generator_tensors(_state_dict_of(model), prefix)
         arr, keep = _lib.host_float_pointers(tensors)
         with torch.cuda.device(self.device):
             check(_lib.lib().gdpso_generator_create(C.byref(self.h), self.meta["z_dim"], self.meta["features_g"],
@@ -123,6 +131,21 @@ class PackedGenerator(_Handle):
 
     def workspace_bytes(self, n):
         return _lib.lib().gdpso_generator_workspace_bytes(self.h, n)
+
+    def forward(self, z: torch.Tensor) -> torch.Tensor:
+        """z [n, z_dim(,1,1)] fp32 or fp64 on the device -> image [n, 1, S, S] in [-1, 1]."""
+        n = z.shape[0]
+        z = z.to(self.device).reshape(n, self.z_dim).contiguous()
+        if z.dtype not in (torch.float32, torch.float64):
+            z = z.float()
+        img = torch.empty(n, self.side, self.side, dtype=torch.float32, device=self.device)
+        img01 = torch.empty_like(img)
+        ws = torch.empty(self.workspace_bytes(n), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            check(_lib.lib().gdpso_generator_forward(self.h, _lib.stream_handle(self.device), n, z.data_ptr(),
+                                                     1 if z.dtype == torch.float64 else 0, img.data_ptr(), img01.data_ptr(),
+                                                     0, 0, ws.data_ptr(), ws.numel()))
+        return img.reshape(n, 1, self.side, self.side)
 
 
 class PackedAssessor(_Handle):
@@ -149,10 +172,10 @@ class PackedEncoder(_Handle):
     """Inverter encoder repacked on the device (gdpso_encoder_create)."""
     _destroy = "gdpso_encoder_destroy"
 
-    def __init__(self, model, device):
+    def __init__(self, model, device, prefix="enc"):
         super().__init__()
         self.device = _device_guard(device)
-        tensors, self.meta = encoder_tensors(_state_dict_of(model))
+        tensors, self.meta = encoder_tensors(_state_dict_of(model), prefix)
         arr, keep = _lib.host_float_pointers(tensors)
         with torch.cuda.device(self.device):
             check(_lib.lib().gdpso_encoder_create(C.byref(self.h), self.meta["enc_dim"], self.meta["features_e"], arr, len(keep)))
@@ -167,6 +190,60 @@ class PackedEncoder(_Handle):
         with torch.cuda.device(self.device):
             check(_lib.lib().gdpso_encoder_forward(self.h, _lib.stream_handle(self.device), n, ptr(x), ptr(out), ptr(ws), ws.numel()))
         return out.reshape(n, self.enc_dim, 1, 1)
+
+
+# ------------------------------------------------------------------ vector quantisation
+def _vq_args(inputs: torch.Tensor, codebook: torch.Tensor):
+    device = _device_guard(codebook.device)
+    if codebook.dim() != 2:
+        raise ValueError("codebook must be [K, D]")
+    cb = codebook.detach().to(torch.float32).contiguous()
+    return device, cb
+
+
+def vq_nearest(inputs: torch.Tensor, codebook: torch.Tensor, want_codes=False, want_dist=False):
+    """Nearest codebook row of every row of ``inputs`` [..., D] (gdpso_vq_nearest).
+    Returns (indices int64 [...], codes [..., D] or None, best distance [...] or None)."""
+    device, cb = _vq_args(inputs, codebook)
+    k, d = cb.shape
+    if inputs.shape[-1] != d:
+        raise RuntimeError(f"shape '[-1, {d}]' is invalid for input of size {inputs.numel()}")  # the reference's view() error
+    x = inputs.detach().to(device, torch.float32).reshape(-1, d).contiguous()
+    n = x.shape[0]
+    idx = torch.empty(n, dtype=torch.int64, device=device)
+    codes = torch.empty(n, d, dtype=torch.float32, device=device) if want_codes else None
+    dist = torch.empty(n, dtype=torch.float32, device=device) if want_dist else None
+    ws = torch.empty(_lib.lib().gdpso_vq_workspace_bytes(k, d), dtype=torch.uint8, device=device)
+    with torch.cuda.device(device):
+        check(_lib.lib().gdpso_vq_nearest(_lib.stream_handle(device), n, d, k, ptr(x), ptr(cb), ptr(idx), ptr(codes), ptr(dist),
+                                          ptr(ws), ws.numel()))
+    lead = inputs.shape[:-1]
+    return (idx.reshape(lead), None if codes is None else codes.reshape(*lead, d), None if dist is None else dist.reshape(lead))
+
+
+def vq_lookup(codebook: torch.Tensor, indices: torch.Tensor) -> torch.Tensor:
+    """codebook[indices] -> [..., D] (gdpso_vq_lookup); IndexError on an index outside the codebook."""
+    device, cb = _vq_args(indices, codebook)
+    k, d = cb.shape
+    idx = indices.detach().to(device, torch.int64).reshape(-1).contiguous()
+    n = idx.shape[0]
+    if n and bool(((idx < 0) | (idx >= k)).any()):
+        raise IndexError("index out of range in self")
+    out = torch.empty(n, d, dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        check(_lib.lib().gdpso_vq_lookup(_lib.stream_handle(device), n, d, k, ptr(cb), ptr(idx), ptr(out)))
+    return out.reshape(*indices.shape, d)
+
+
+def vq_seed_codebook(codebook: torch.Tensor, positions: torch.Tensor, row0: int = 0):
+    """In place: codebook[row0 : row0+n] = float32(positions [n, D] float64 on the device)."""
+    device = _device_guard(codebook.device)
+    if codebook.dtype != torch.float32 or not codebook.is_contiguous():
+        raise ValueError("codebook must be a contiguous float32 tensor")
+    k, d = codebook.shape
+    pos = positions.detach().to(device, torch.float64).reshape(-1, d).contiguous()
+    with torch.cuda.device(device):
+        check(_lib.lib().gdpso_vq_seed_codebook(_lib.stream_handle(device), ptr(codebook), k, d, int(row0), ptr(pos), pos.shape[0]))
 
 
 # -------------------------------------------------------------------- fitness settings

@@ -13,8 +13,12 @@ from torch import nn
 
 
 class ParamTree(nn.Module):
-    def __init__(self, rows):
+    def __init__(self, rows, nodes=None):
+        """``nodes``: optional {top-level name: nn.Module} used as containers instead of bare
+        ``nn.Module()`` ones (e.g. callable sub-networks)."""
         super().__init__()
+        for name, module in (nodes or {}).items():
+            self.add_module(name, module)
         for key, shape, kind in rows:
             *path, leaf = key.split(".")
             node = self

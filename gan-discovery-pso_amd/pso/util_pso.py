@@ -140,6 +140,7 @@ class Swarm:
             np.random.set_state(rng_state)
             np.random.random((iters, n, 2))
         self.results = res
+        self._device_pos = sw.pos if comm is None else None
         self._publish(res, n, targets)
 
         history = {"mean_mse": [float(x) for x in res.get("mean_mse", [])], "global_best_val": []}
@@ -171,6 +172,16 @@ class Swarm:
                 p.history = list(res["hist_pos"][:, k, :])
                 p.history_vel = list(res["hist_vel"][:, k, :])
             self.swarm.append(p)
+
+    def final_positions(self):
+        """Positions after the last move as a float64 [N, D] tensor on the device (not in the
+        reference, which goes through pickled histories: training/vq_vae.py:42-48 takes the last
+        history row of every particle; this is that row without leaving HBM)."""
+        if self.results is None:
+            raise RuntimeError("optimize() has not been run")
+        if getattr(self, "_device_pos", None) is not None:
+            return self._device_pos
+        return torch.from_numpy(np.ascontiguousarray(self.results["pos"])).to(self.device)
 
     def checkpoint(self):
         """{particle_k: DataFrame(history)} and the same for velocities (reference util_pso.py:159-165)."""

@@ -131,6 +131,20 @@ def encoder_state(enc_dim: int, channels_img: int = 1, features_e: int = 64, *, 
     return sd
 
 
+def vqvae_gan_state(embedded_dim: int, features_g: int = 64, features_d: int = 64, *, seed: int = 4) -> dict:
+    """State dict of VectorQuantizedVAE_GAN without its codebook (reference
+    src/inverter/utils_vq_vae/util_model.py:273-289): the inverter encoder with a BatchNorm
+    after the second convolution under ``encoder.*`` and the generator stack under ``decoder.*``."""
+    rs = np.random.RandomState(seed)
+    sd: dict = {}
+    for k, v in encoder_state(embedded_dim, 1, features_d, seed=seed + 1000).items():
+        sd["encoder." + k[len("enc."):]] = v
+    _bn(rs, features_d * 2, "encoder.2.1", sd, True)
+    for k, v in generator_state(embedded_dim, 1, features_g, seed=seed + 2000).items():
+        sd["decoder." + k[len("gen."):]] = v
+    return sd
+
+
 def to_torch(sd: dict):
     """numpy state dict -> dict of torch CPU tensors (same keys)."""
     import torch

@@ -36,21 +36,7 @@ class Generator(ParamTree):
         return self.packed(lambda m: engine.PackedGenerator(m, dev), extra=(str(dev),))
 
     def forward(self, x):
-        n = x.shape[0]
-        gen = self.device_handle(x.device)
-        z = x.reshape(n, self.z_dim).contiguous()
-        if z.dtype not in (torch.float32, torch.float64):
-            z = z.float()
-        side = gen.side
-        img = torch.empty(n, side, side, dtype=torch.float32, device=x.device)
-        img01 = torch.empty_like(img)
-        ws = torch.empty(gen.workspace_bytes(n), dtype=torch.uint8, device=x.device)
-        L = engine._lib
-        with torch.cuda.device(x.device):
-            L.check(L.lib().gdpso_generator_forward(gen.h, L.stream_handle(x.device), n, z.data_ptr(),
-                                                    1 if z.dtype == torch.float64 else 0, img.data_ptr(), img01.data_ptr(),
-                                                    0, 0, ws.data_ptr(), ws.numel()))
-        return img.reshape(n, 1, side, side)
+        return self.device_handle(x.device).forward(x)
 
 
 def load_gan(model_dir, z_dim, channel, units_gen, device):

@@ -113,7 +113,10 @@ int gdpso_assessor_forward(const gdpso_assessor *a, void *stream, int n, const f
  * Replaces Encoder.forward, reference src/inverter/utils_ae/util_inverter.py:164-184
  * (used once to seed particle positions, src/pso/util_pso.py:93-112).
  * `tensors` (HOST): enc.0.weight [F,1,4,4], enc.0.bias, enc.2.0.weight [2F,F,4,4],
- * enc.2.0.bias, enc.3.weight [Z,2F,7,7], enc.3.bias. */
+ * enc.2.0.bias, enc.3.weight [Z,2F,7,7], enc.3.bias.  With n_tensors = 10 four more arrays
+ * follow (weight, bias, running_mean, running_var of a BatchNorm2d(2F) after the second
+ * convolution): the encoder of VectorQuantizedVAE_GAN, reference
+ * src/inverter/utils_vq_vae/util_model.py:273-279,294-299. */
 typedef struct gdpso_encoder gdpso_encoder;
 int gdpso_encoder_create(gdpso_encoder **out, int enc_dim, int features_e, const float *const *tensors,
                          int n_tensors);
@@ -218,6 +221,31 @@ typedef struct {
 
 int gdpso_swarm_iterate(const gdpso_swarm *s, const gdpso_generator *g, const gdpso_assessor *a,
                         const gdpso_run *r, void *stream, int first_iteration, int n_iterations);
+
+/* ------------------------------------------------------- vector quantisation (VQ-VAE)
+ * The step after the PSO run in the reference's VQ-VAE workflow.  All buffers on the device,
+ * row-major fp32 unless noted; `codebook` is [k, d] (nn.Embedding(K, D).weight).
+ *
+ * gdpso_vq_seed_codebook: rows [row0, row0+n) of the codebook = float32(positions [n, d],
+ * float64): the last-iteration positions of one swarm, as gathered per class by
+ * upload_pso_disentangled_space (reference src/training/vq_vae.py:35-57) and written into
+ * the embedding by pso_weights (src/inverter/utils_vq_vae/util_model.py:49-54,125-132).
+ *
+ * gdpso_vq_nearest: replaces VectorQuantization.forward, reference
+ * src/inverter/utils_vq_vae/util_function.py:6-23: distances (|c|^2 + |x|^2) - 2 x.c^T in
+ * fp32, indices[i] (int64) = arg-min over the k codes, lowest index among equal distances, a
+ * NaN distance taking precedence like torch.min.  Optional outputs: codes [n, d] =
+ * codebook[indices] (VectorQuantizationStraightThrough.forward, :34-44) and best_dist [n].
+ * d <= 4096.  workspace: gdpso_vq_workspace_bytes(k, d).
+ *
+ * gdpso_vq_lookup: codes[i] = codebook[indices[i]] (the embedding lookup of
+ * VectorQuantizedVAE_GAN.decode, util_model.py:313-316); an index outside [0, k) gives a row
+ * of NaN. */
+size_t gdpso_vq_workspace_bytes(int k, int d);
+int gdpso_vq_seed_codebook(void *stream, float *codebook, int k, int d, int row0, const double *positions, int n);
+int gdpso_vq_nearest(void *stream, int n, int d, int k, const float *inputs, const float *codebook,
+                     long long *indices, float *codes, float *best_dist, void *workspace, size_t workspace_bytes);
+int gdpso_vq_lookup(void *stream, int n, int d, int k, const float *codebook, const long long *indices, float *codes);
 
 /* -------------------------------------------------------------------- measurement
  * No counterpart in the reference: a hook for benchmarks.  Between begin and end, every

@@ -110,6 +110,51 @@ def encoder_forward(sd: dict, x: torch.Tensor) -> torch.Tensor:
     return F.conv2d(x, sd["enc.3.weight"], sd["enc.3.bias"], 2, 0)
 
 
+def vq_distances(inputs: torch.Tensor, codebook: torch.Tensor) -> torch.Tensor:
+    """[n, D] x [K, D] -> squared distances [n, K] as (|c|^2 + |x|^2) - 2 x.c^T in fp32
+    (reference src/inverter/utils_vq_vae/util_function.py:12-17)."""
+    flat = inputs.reshape(-1, codebook.shape[1])
+    csq = torch.sum(codebook ** 2, dim=1)
+    xsq = torch.sum(flat ** 2, dim=1, keepdim=True)
+    return torch.addmm(csq + xsq, flat, codebook.t(), alpha=-2.0, beta=1.0)
+
+
+def vq_nearest(inputs: torch.Tensor, codebook: torch.Tensor):
+    """Nearest code per row of ``inputs`` [..., D]: (indices [...], codes [..., D]); the first
+    of equal minima wins (reference util_function.py:19-20 and :34-44)."""
+    d = vq_distances(inputs, codebook)
+    idx = torch.min(d, dim=1)[1]
+    codes = torch.index_select(codebook, 0, idx).view_as(inputs)
+    return idx.view(*inputs.shape[:-1]), codes
+
+
+def seed_codebook(last_positions) -> np.ndarray:
+    """Codebook rows from the last-iteration positions of the swarms, one float64 [N, D] block per
+    class in class order: cast to float32 and stacked (reference src/training/vq_vae.py:42-56,
+    then util_model.py:49-54)."""
+    return np.concatenate([np.asarray(p, dtype=np.float64).astype(np.float32) for p in last_positions], axis=0)
+
+
+def vqvae_gan_encoder_forward(sd: dict, x: torch.Tensor) -> torch.Tensor:
+    """Encoder of VectorQuantizedVAE_GAN (reference util_model.py:273-279): the inverter encoder
+    with an eval-mode BatchNorm before the second LeakyReLU."""
+    x = F.leaky_relu(F.conv2d(x, sd["encoder.0.weight"], sd["encoder.0.bias"], 2, 1), 0.2)
+    x = F.conv2d(x, sd["encoder.2.0.weight"], sd["encoder.2.0.bias"], 2, 1)
+    x = F.leaky_relu(_bn_eval(x, sd, "encoder.2.1"), 0.2)
+    return F.conv2d(x, sd["encoder.3.weight"], sd["encoder.3.bias"], 2, 0)
+
+
+def vqvae_gan_forward(sd: dict, codebook: torch.Tensor, x: torch.Tensor):
+    """(x_tilde, z_e_x, z_q_x, latents) of VectorQuantizedVAE_GAN.forward / encode (reference
+    util_model.py:308-322), inference values only."""
+    z_e_x = vqvae_gan_encoder_forward(sd, x)
+    nhwc = z_e_x.permute(0, 2, 3, 1).contiguous()
+    latents, codes = vq_nearest(nhwc, codebook)
+    z_q_x = codes.permute(0, 3, 1, 2).contiguous()
+    gsd = {"gen." + k[len("decoder."):]: v for k, v in sd.items() if k.startswith("decoder.")}
+    return generator_forward(gsd, z_q_x), z_e_x, z_q_x, latents
+
+
 def fitness_from_logits(logits: torch.Tensor, class_index: int, mode: str, threshold: float,
                         eps: float) -> torch.Tensor:
     """logits [B,n_class] -> fitness [B] fp32.

@@ -8,7 +8,8 @@ plain data (.npz: inputs and the reference's outputs) and are what travels.  Usa
 
 How the reference is imported: its library modules ``src.pso.util_pso``,
 ``src.pso.util_discovery``, ``src.pso.util_cnn``, ``src.utils.util_dcgan``,
-``src.inverter.utils_ae.util_inverter`` and ``src.hands_on.pso`` are imported from
+``src.inverter.utils_ae.util_inverter``, ``src.inverter.utils_vq_vae.util_function`` /
+``util_model`` and ``src.hands_on.pso`` are imported from
 /root/reference unchanged.  Some of them import, at module level, plotting / logging /
 dataset packages that are not installed here (torchvision, tensorboard, torchsummary,
 cv2, natsort, openpyxl, seaborn, plotly); none of those touch the arithmetic, so inert
@@ -87,6 +88,8 @@ def import_reference():
     mods.util_dcgan = importlib.import_module("src.utils.util_dcgan")
     mods.util_inverter = importlib.import_module("src.inverter.utils_ae.util_inverter")
     mods.util_pso_inverter = importlib.import_module("src.inverter.utils_ae.util_pso_inverter")
+    mods.vq_function = importlib.import_module("src.inverter.utils_vq_vae.util_function")
+    mods.vq_model = importlib.import_module("src.inverter.utils_vq_vae.util_model")
     sys.path.insert(0, os.path.join(REF, "src"))
     mods.toy = importlib.import_module("hands_on.pso")
     # side effects only: image grid + 400 dpi PNG per iteration
@@ -263,6 +266,62 @@ def fx_big_input(ref):
     save("assessor_shapes", **out)
 
 
+def fx_vq(ref):
+    """Codebook seeding and nearest-code lookup (reference util_model.py:49-54,125-148,268-322;
+    util_function.py:6-44; the position gathering of training/vq_vae.py:42-56 restated with
+    in-memory histories instead of pickles)."""
+    import pandas as pd
+    out = {}
+    # (A) the workflow's shape: 8 classes x 32 particles = 256 codes of 100 dims
+    rs = np.random.RandomState(101)
+    n_cls, n_part, d, t = 8, 32, 100, 3
+    hist = rs.standard_normal((n_cls, n_part, t, d))  # float64 position histories, last row = final position
+    data = np.array([], dtype="float32")
+    for c in range(n_cls):
+        history_particles = {f"particle_{k}": pd.DataFrame(hist[c, k]) for k in range(n_part)}
+        data_iid = np.ones((n_part, d), dtype="float32")
+        for particle_idx, p_key in enumerate(history_particles.keys()):
+            data_iid[particle_idx, :] = history_particles[p_key].iloc[-1, :]
+        data = data_iid.copy() if data.size == 0 else np.concatenate([data, data_iid], axis=0)
+    data_pso = pd.DataFrame(data)
+    model = ref.vq_model.get_model("vqvae_dcgan", 1, d, n_cls * n_part, data_pso, features_g=64, features_d=64)
+    wsd = synth.vqvae_gan_state(d, 64, 64, seed=41)
+    sd = synth.to_torch(wsd)
+    sd["codebook.embedding.weight"] = model.codebook.embedding.weight.detach().clone()
+    model.load_state_dict(sd)
+    model.eval()
+    x = np.tanh(rs.standard_normal((24, 1, 28, 28))).astype(np.float32)
+    with torch.no_grad():
+        xt = torch.from_numpy(x)
+        latents = model.encode(xt)
+        x_tilde, z_e_x, z_q_x = model(xt)
+        dec = model.decode(latents)
+        # inputs close to codes (what a trained encoder produces): codes + small noise
+        near = model.codebook.embedding.weight[rs.randint(0, 256, 64)] + 0.05 * torch.from_numpy(rs.standard_normal((64, d)).astype(np.float32))
+        near_idx = ref.vq_function.vq(near, model.codebook.embedding.weight)
+    out.update(A_final_positions=hist[:, :, -1, :], A_codebook=model.codebook.embedding.weight.detach().numpy(),
+               A_x=x, A_latents=latents.numpy(), A_x_tilde=x_tilde.numpy(), A_z_e_x=z_e_x.numpy(), A_z_q_x=z_q_x.numpy(),
+               A_decode=dec.numpy(), A_near=near.numpy(), A_near_idx=near_idx.numpy(), A_seed=41, A_ck=synth.checksum(wsd))
+    # (B) the bare functions on a feature map: inputs [2,5,5,16], 37 codes, two pairs of identical codes
+    cb = rs.standard_normal((37, 16)).astype(np.float32)
+    cb[20] = cb[5]
+    cb[36] = cb[0]
+    inp = rs.standard_normal((2, 5, 5, 16)).astype(np.float32)
+    inp[0, 0, 0] = cb[5]   # exactly on a duplicated code
+    inp[1, 4, 4] = cb[36] * 1.01
+    with torch.no_grad():
+        idx = ref.vq_function.vq(torch.from_numpy(inp), torch.from_numpy(cb))
+        codes, idx_flat = ref.vq_function.vq_st(torch.from_numpy(inp), torch.from_numpy(cb))
+        emb = ref.vq_model.VQEmbedding(37, 16, None)
+        emb.embedding.weight.data = torch.from_numpy(cb)
+        nchw = torch.from_numpy(inp).permute(0, 3, 1, 2).contiguous()
+        e_lat = emb(nchw)
+        e_st, e_bar = emb.straight_through(nchw)
+    out.update(B_codebook=cb, B_inputs=inp, B_idx=idx.numpy(), B_codes=codes.numpy(), B_idx_flat=idx_flat.numpy(),
+               B_emb_latents=e_lat.numpy(), B_emb_st=e_st.numpy(), B_emb_bar=e_bar.numpy())
+    save("vq", **out)
+
+
 FIXTURES = {
     "layers": lambda r: fx_layers(r),
     "swarm_n8_t5_z10": lambda r: fx_swarm(r, "swarm_n8_t5_z10", 8, 5, 10, (0.73, 1.496, 1.496), False, False, 42),
@@ -273,6 +332,7 @@ FIXTURES = {
                                                label=7, tolerance=2e-3),
     "inverter_in_n8_t5": lambda r: fx_inverter(r, "inverter_in_n8_t5", "optimize_in_training", 8, 5, 10, 9),
     "inverter_out_n8_t5": lambda r: fx_inverter(r, "inverter_out_n8_t5", "optimize_out_training", 8, 5, 10, 9),
+    "vq": lambda r: fx_vq(r),
     "toy_sphere": lambda r: fx_toy(r),
     "assessor_shapes": lambda r: fx_big_input(r),
 }

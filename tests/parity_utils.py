@@ -28,3 +28,13 @@ def first_ambiguous_iteration(fitness: np.ndarray, tau: float) -> int:
                 return t
             gbest = best
     return t_n
+
+
+def vq_margins(distances: np.ndarray) -> np.ndarray:
+    """Gap between the smallest and the second smallest DISTINCT-code distance of every row
+    of ``distances`` [n, K]; exact duplicates of the winner are not counted (they tie by
+    construction and are decided by the lowest-index rule)."""
+    d = np.sort(distances, axis=1)
+    gap = d[:, 1:] - d[:, :1]
+    gap = np.where(gap == 0, np.inf, gap)
+    return gap.min(axis=1)

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from parity_utils import first_ambiguous_iteration
+from parity_utils import first_ambiguous_iteration, vq_margins
 
 TOL = 1e-4  # the contract: fp32 outputs within 1e-4 of the reference CPU path
 
@@ -151,3 +151,37 @@ def test_assessor_shapes(oracle, synth):
             np.testing.assert_allclose(oracle.resnet_forward(csd, x).numpy(), g[f"{model}_logits64"], rtol=1e-4, atol=1e-4)
             np.testing.assert_allclose(oracle.resnet_forward(csd, x[:, :, :28, :28].contiguous()).numpy(),
                                        g[f"{model}_logits28"], rtol=1e-4, atol=1e-4)
+
+
+def test_vq(oracle, synth):
+    """Codebook seeding, nearest-code lookup and the VQ-VAE-GAN inference path against the
+    reference's outputs (tests/golden/vq.npz)."""
+    g = load_golden("vq")
+    # seeding: float32 cast of the final positions, class blocks stacked
+    cb = oracle.seed_codebook(list(g["A_final_positions"]))
+    np.testing.assert_array_equal(cb, g["A_codebook"])
+    wsd = synth.vqvae_gan_state(100, 64, 64, seed=int(g["A_seed"]))
+    assert synth.checksum(wsd) == str(g["A_ck"])
+    sd, cbt = synth.to_torch(wsd), torch.from_numpy(cb)
+    with torch.no_grad():
+        x_tilde, z_e_x, z_q_x, latents = oracle.vqvae_gan_forward(sd, cbt, torch.from_numpy(g["A_x"]))
+        np.testing.assert_allclose(z_e_x.numpy(), g["A_z_e_x"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_array_equal(latents.numpy(), g["A_latents"])
+        np.testing.assert_array_equal(z_q_x.numpy(), g["A_z_q_x"])
+        np.testing.assert_allclose(x_tilde.numpy(), g["A_x_tilde"], atol=TOL)
+        np.testing.assert_allclose(g["A_decode"], g["A_x_tilde"], atol=1e-6)  # decode(encode(x)) is the same image
+        idx, _ = oracle.vq_nearest(torch.from_numpy(g["A_near"]), cbt)
+        np.testing.assert_array_equal(idx.numpy(), g["A_near_idx"])
+        # the fixtures' decisions are not near-ties: an fp32 reordering cannot flip them
+        m = vq_margins(oracle.vq_distances(torch.from_numpy(g["A_z_e_x"]).reshape(-1, 100), cbt).numpy())
+        assert m.min() > 1e-2, m.min()
+        # the bare functions on a feature map, duplicated codes included (first index wins)
+        cb2, inp = torch.from_numpy(g["B_codebook"]), torch.from_numpy(g["B_inputs"])
+        idx, codes = oracle.vq_nearest(inp, cb2)
+        np.testing.assert_array_equal(idx.numpy(), g["B_idx"])
+        np.testing.assert_array_equal(codes.numpy(), g["B_codes"])
+        np.testing.assert_array_equal(idx.reshape(-1).numpy(), g["B_idx_flat"])
+        assert g["B_idx"][0, 0, 0] == 5 and g["B_idx"][1, 4, 4] == 0
+        np.testing.assert_array_equal(g["B_emb_latents"], g["B_idx"])
+        np.testing.assert_array_equal(g["B_emb_st"], np.transpose(g["B_codes"], (0, 3, 1, 2)))
+        np.testing.assert_array_equal(g["B_emb_bar"], g["B_emb_st"])
