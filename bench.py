@@ -175,6 +175,7 @@ def main():
         lib.check(L.gdpso_conv_timing_end(C.byref(ms), C.byref(launches), C.byref(flops)))
         achieved = flops.value / (ms.value * 1e-3) / 1e12
         alg_bytes = L.gdpso_conv_timing_bytes() / launches.value
+        executed = L.gdpso_conv_timing_executed_flops()
         # HBM bytes per launch from the committed PMC passes of this same command (counters cannot be
         # read from inside the process); null when the summary is absent or was taken at another size
         traffic = None
@@ -192,7 +193,10 @@ def main():
                     "algorithmic_bytes_per_launch": round(alg_bytes),
                     "launches_per_step": launches.value // k, "avg_launch_us": round(1e3 * ms.value / launches.value, 3),
                     "conv_ms_per_step": round(ms.value / k, 4),
-                    "algorithmic_gflop_per_step": round(flops.value / k / 1e9, 3)}
+                    "algorithmic_gflop_per_step": round(flops.value / k / 1e9, 3),
+                    # what the MFMAs really multiplied: taps of border pixels that fall in the padding are skipped
+                    "executed_gflop_per_step": round(executed / k / 1e9, 3),
+                    "executed_frac": round(executed / (ms.value * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
     if comm is not None:
         comm.dist.barrier()
 

@@ -25,29 +25,37 @@ int fail(int code, const std::string &msg);
     } while (0)
 
 constexpr int MAX_TAPS = 64;   // 7x7 = 49 is the largest window on the path
-constexpr int MAX_PHASES = 4;  // sub-pixel phases of a stride-2 transposed convolution
+constexpr int MAX_PHASES = 16; // 3x3 border classes of a padded convolution, or 4 sub-pixel phases x 2x2 classes
+constexpr int PHASE_HDR = 12;  // ints ahead of the taps in a phase's device table
 
 // Activation applied in a convolution's epilogue.
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY02 = 2 };
 
 // One convolution (or one transposed convolution split into sub-pixel phases) expressed as
-// an implicit GEMM over NHWC activations:
-//   out[pix(m), co] = act( scale[co] * sum_{t,ci} in[n, my*in_stride + dy[t], mx*in_stride + dx[t], ci]
-//                                               * wt[co][t*cin + ci]  + shift[co] (+ res[pix(m), co]) )
-// with m = (n, my, mx) over an hm x wm grid and pix(m) = (n, my*out_mul + off_y, mx*out_mul + off_x).
-// Taps that fall outside the input read zeros.  Only taps that can ever be in range are kept.
+// an implicit GEMM over NHWC activations.  The output is covered by `nphase` phases; phase p
+// owns the output pixels (my*out_mul + off_y, mx*out_mul + off_x), (my, mx) over its own
+// hm x wm grid, and computes
+//   out[pix, co] = act( scale[co] * sum_{t,ci} in[n, my*in_stride + in_y0 + dy[t], mx*in_stride + in_x0 + dx[t], ci]
+//                                             * wt[wt_offset + co*wstride + wtap[t]*cin + ci]  + shift[co] (+ res[pix, co]) )
+// Taps that fall outside the input read zeros.  A padded convolution is split into border
+// classes (runs of output rows / columns with the same set of in-range taps), each a phase
+// whose tap list holds only taps that are in range for all of its pixels; the classes share
+// one weight matrix.
 struct ConvPhase {
     int ntaps;
     int off_y, off_x;      // output offset of this phase
-    long wt_offset;        // element offset of this phase's [cout][ntaps*cin] matrix
+    int hm, wm;            // output sub-grid of this phase
+    int in_y0, in_x0;      // input origin of this phase
+    long wt_offset;        // element offset of this phase's [cout][wstride] weight matrix
+    int wstride;           // floats per output channel in that matrix
     int8_t dy[MAX_TAPS];
     int8_t dx[MAX_TAPS];
+    int16_t wtap[MAX_TAPS];  // where the tap's cin weights start in a weight row, in units of cin
 };
 
 struct ConvLayer {
     int cin, cout;
     int hin, win;
-    int hm, wm;
     int hout, wout;
     int in_stride, out_mul;
     int nphase;
@@ -56,7 +64,8 @@ struct ConvLayer {
     const float *wt;     // device
     const float *scale;  // device [cout] (never null)
     const float *shift;  // device [cout]
-    const int *table;    // device [nphase][4 + MAX_TAPS]: {ntaps, off_y, off_x, wt_offset, (dy | dx<<16)...}
+    const int *table;    // device [nphase][PHASE_HDR + MAX_TAPS], see upload_conv
+    size_t weight_floats;  // size of the packed weights
     // launch plan (chosen once per batch size by plan_conv)
     int tile;            // 128 or 64
     int splits;          // split-K factor

@@ -17,6 +17,12 @@
 // BK = 32, two LDS buffers, register prefetch of the next K-tile, one barrier per K-tile.
 // Small-M layers (late ResNet stages at 1x1..4x4) use 64x64 tiles plus split-K over
 // blockIdx.z with fp32 partial slabs and a fused reduce+epilogue kernel.
+//
+// A layer is a list of phases, each an output sub-grid with its own tap list.  Padded
+// convolutions are split into border classes (first / middle / last output rows x columns):
+// inside a class every tap is in range for every row, so the taps that would only multiply
+// padding zeros are not in its list at all.  On the small maps of the late ResNet stages
+// that is most of the nominal work (a 3x3 convolution on a 2x2 map has 4 live taps of 9).
 #include <hip/hip_ext.h>
 
 #include <cstdlib>
@@ -28,10 +34,13 @@ namespace gdpso {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+// Operand loads name the global address space: a generic (flat) load also counts against
+// lgkmcnt, so the LDS waits ahead of each barrier would drain the prefetch as well.
+using global_f32x4_ptr = const __attribute__((address_space(1))) f32x4 *;
 
 constexpr int BK = 32;
 constexpr int LDA = BK + 4;  // 144-byte rows: ds_read_b128 of 16 consecutive rows is conflict-free
-constexpr int PHASE_TABLE_INTS = 4 + MAX_TAPS;  // {ntaps, off_y, off_x, wt_offset, taps...}
+constexpr int PHASE_TABLE_INTS = PHASE_HDR + MAX_TAPS;  // header (see upload_conv) + packed taps
 
 struct ConvKArgs {
     const float *in;
@@ -43,13 +52,20 @@ struct ConvKArgs {
     float *part;       // split-K slabs [splits][pixels][cout], or null
     int *counters;     // split-K arrival counters, one per output tile (zero between launches), or null
     const int *table;  // [nphase][PHASE_TABLE_INTS]
-    int M, hm, wm;
+    int n_images;
     int hin, win, cin;
     int cout, hout, wout;
     int in_stride, out_mul;
-    int act, splits, ksplit;
+    int act, splits;
     int tiles_n;
     long slab;  // elements per split-K slab
+    int tile_end[MAX_PHASES];  // running count of M-tiles up to and including each phase (INT_MAX past the last)
+};
+
+// What a workgroup needs to know about its phase (all wave-uniform).
+struct PhaseInfo {
+    int M, hm, wm;      // rows of this phase = n_images * hm * wm
+    int off_y, off_x;   // output pixel = (my * out_mul + off_y, mx * out_mul + off_x)
 };
 
 // Taps that fall into the padding (and tail rows past M) read from here instead of
@@ -68,13 +84,13 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // (lds_floats long); every operand read from it must have been retired by a barrier.
 template <int BM, int BN>
 __device__ __forceinline__ void conv_epilogue(const ConvKArgs &a, float *lds, int lds_floats,
-                                              f32x16 (&acc)[BM / 64][BN / 64], int tid, int m0, int n0, int ph, int sp,
-                                              int nt, int tile, int off_y, int off_x) {
+                                              f32x16 (&acc)[BM / 64][BN / 64], int tid, int m0, int n0, int sp, int tile,
+                                              const PhaseInfo &P) {
     constexpr int WM = BM / 64, WN = BN / 64;
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int l31 = lane & 31, half = lane >> 5;
-    const int hw = a.hm * a.wm;
+    const int hw = P.hm * P.wm;
     // Epilogue through LDS.  Accumulator register r of lane l is
     // C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]; the tile is first laid out row-major
     // in LDS (the K loop's last barrier has retired every operand read), then written with
@@ -98,19 +114,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs &a, float *lds, in
     const int col = n0 + c4 * 4;
     const bool direct = a.splits == 1;
     const f32x4 sc = *(const f32x4 *)(a.scale + col), sh = *(const f32x4 *)(a.shift + col);
-    const bool remap = a.out_mul != 1 || a.hm != a.hout || a.wm != a.wout;
+    const bool remap = a.out_mul != 1 || P.hm != a.hout || P.wm != a.wout;
     // element offset of this thread's 4 channels in each of its rows (-1: row past M)
     long off[PASSES];
 #pragma unroll
     for (int pass = 0; pass < PASSES; ++pass) {
         const int m = m0 + pass * RPP + r0;
         size_t pix = (size_t)m;
-        if (remap && m < a.M) {
+        if (remap && m < P.M) {
             const int n = m / hw, rr = m - n * hw;
-            const int my = rr / a.wm, mx = rr - my * a.wm;
-            pix = ((size_t)n * a.hout + my * a.out_mul + off_y) * a.wout + mx * a.out_mul + off_x;
+            const int my = rr / P.wm, mx = rr - my * P.wm;
+            pix = ((size_t)n * a.hout + my * a.out_mul + P.off_y) * a.wout + mx * a.out_mul + P.off_x;
         }
-        off[pass] = m < a.M ? (long)(pix * a.cout + col) : -1;
+        off[pass] = m < P.M ? (long)(pix * a.cout + col) : -1;
     }
     if (direct) {
 #pragma unroll
@@ -152,7 +168,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs &a, float *lds, in
     __syncthreads();
     int *s_last = (int *)&lds[lds_floats - 4];  // past the output tile
     if (tid == 0) {
-        int *cnt = a.counters + ph * nt + tile;
+        int *cnt = a.counters + tile;
         const int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = ticket == a.splits - 1;
         if (last) {
@@ -195,47 +211,70 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKArgs a) {
     const int nt = gridDim.x, xq = nt >> 3, xr = nt & 7;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + slot;
-    const int tm = tile / a.tiles_n, tn = tile - tm * a.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int ph = blockIdx.z / a.splits, sp = blockIdx.z - ph * a.splits;
+    const int tmg = tile / a.tiles_n, tn = tile - tmg * a.tiles_n;
+    // phase of this M-tile: the last one whose predecessors end at or before it
+    int ph = 0, tm_base = 0;
+#pragma unroll
+    for (int p = 0; p < MAX_PHASES - 1; ++p)
+        if (tmg >= a.tile_end[p]) {
+            ph = p + 1;
+            tm_base = a.tile_end[p];
+        }
+    const int m0 = (tmg - tm_base) * BM, n0 = tn * BN;
+    const int sp = blockIdx.z;
     const int *tab = a.table + ph * PHASE_TABLE_INTS;
-    const int ntaps = tab[0], off_y = tab[1], off_x = tab[2];
+    const int ntaps = tab[0];
+    PhaseInfo P;
+    P.off_y = tab[1];
+    P.off_x = tab[2];
+    P.hm = tab[4];
+    P.wm = tab[5];
+    P.M = a.n_images * P.hm * P.wm;
+    const int in_y0 = tab[6], in_x0 = tab[7], wstride = tab[8];
     const float *wt = a.wt + tab[3];
     const int ktot = ntaps * a.cin;
-    const int kbeg = sp * a.ksplit;
-    const int kend = min(ktot, kbeg + a.ksplit);
+    const int ksplit = ((ktot / BK + a.splits - 1) / a.splits) * BK;  // this phase's K range per split
+    const int kbeg = sp * ksplit;
+    const int kend = min(ktot, kbeg + ksplit);
 
     // loader coordinates: 8 threads x 16 B cover one 32-float row
     const int lrow = tid >> 3, lcol = (tid & 7) * 4;
     int a_iy0[PA], a_ix0[PA], a_img[PA];
     bool a_ok[PA];
-    const int hw = a.hm * a.wm;
+    const int hw = P.hm * P.wm;
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
         const int m = m0 + lrow + 32 * p;
-        a_ok[p] = m < a.M;
+        a_ok[p] = m < P.M;
         const int mm = a_ok[p] ? m : 0;
         const int n = mm / hw, r = mm - n * hw;
-        const int my = r / a.wm, mx = r - my * a.wm;
-        a_iy0[p] = my * a.in_stride;
-        a_ix0[p] = mx * a.in_stride;
+        const int my = r / P.wm, mx = r - my * P.wm;
+        a_iy0[p] = my * a.in_stride + in_y0;
+        a_ix0[p] = mx * a.in_stride + in_x0;
         a_img[p] = n * a.hin * a.win;
     }
     // Gather pointers advance by one K-tile (32 channels) per load and are recomputed only
-    // when the K range crosses into the next tap.  Rows whose tap falls in the padding (and
-    // tail rows past M) point into the zero page and advance like the others.
+    // when the K range crosses into the next tap.  Rows whose tap falls in the padding (only
+    // in layers too irregular to be split into border classes) and tail rows past M point
+    // into the zero page and advance like the others.  A tap entry is
+    // dy | dx << 8 | (position of the tap in the weight rows) << 16.
     const float *aptr[PA], *bptr[PB];
+    const float *brow[PB];
+#pragma unroll
+    for (int p = 0; p < PB; ++p) brow[p] = wt + (size_t)(n0 + lrow + 32 * p) * wstride + lcol;
     int tap = kbeg / a.cin, ci0 = kbeg - tap * a.cin;
 #define GDPSO_SET_TAP(CI)                                                                                       \
     {                                                                                                           \
-        const int packed_ = tab[4 + tap];                                                                       \
-        const int dy_ = (int)(short)(packed_ & 0xffff), dx_ = packed_ >> 16;                                    \
+        const int packed_ = tab[PHASE_HDR + tap];                                                               \
+        const int dy_ = (int)(signed char)(packed_ & 0xff), dx_ = (int)(signed char)((packed_ >> 8) & 0xff);    \
+        const int wk_ = (packed_ >> 16) * a.cin + (CI);                                                         \
         _Pragma("unroll") for (int p = 0; p < PA; ++p) {                                                        \
             const int iy = a_iy0[p] + dy_, ix = a_ix0[p] + dx_;                                                 \
             const bool ok = a_ok[p] && (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;        \
             aptr[p] = ok ? a.in + (size_t)(a_img[p] + iy * a.win + ix) * a.cin + (CI) + lcol                    \
                          : g_zero_page + (CI) + lcol;                                                           \
         }                                                                                                       \
+        _Pragma("unroll") for (int p = 0; p < PB; ++p) bptr[p] = brow[p] + wk_;                                 \
     }
     // Prefetch registers for the next K-tile.  Native vector types over fully unrolled loops:
     // with HIP's float4 struct these arrays were not promoted to registers (they went to
@@ -244,11 +283,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKArgs a) {
 #define GDPSO_GLOAD()                                                                                           \
     {                                                                                                           \
         _Pragma("unroll") for (int p = 0; p < PA; ++p) {                                                        \
-            ra[p] = *(const f32x4 *)aptr[p];                                                                    \
+            ra[p] = *(global_f32x4_ptr)aptr[p];                                                                  \
             aptr[p] += BK;                                                                                      \
         }                                                                                                       \
         _Pragma("unroll") for (int p = 0; p < PB; ++p) {                                                        \
-            rb[p] = *(const f32x4 *)bptr[p];                                                                    \
+            rb[p] = *(global_f32x4_ptr)bptr[p];                                                                  \
             bptr[p] += BK;                                                                                      \
         }                                                                                                       \
         ci0 += BK;                                                                                              \
@@ -281,8 +320,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKArgs a) {
 
     if (kbeg < kend) {
         GDPSO_SET_TAP(ci0)
-#pragma unroll
-        for (int p = 0; p < PB; ++p) bptr[p] = wt + (size_t)(n0 + lrow + 32 * p) * ktot + kbeg + lcol;
         GDPSO_GLOAD()
         GDPSO_SSTORE(0)
     }
@@ -327,177 +364,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKArgs a) {
 #undef GDPSO_SSTORE
 #undef GDPSO_LOADFRAG
 
-    conv_epilogue<BM, BN>(a, lds, 2 * (BM + BN) * LDA, acc, tid, m0, n0, ph, sp, nt, tile, off_y, off_x);
-}
-
-// ---------------------------------------------------------------------------------
-// Direct-to-LDS variant of the kernel above: the K-tiles of both operands travel
-// global -> LDS with global_load_lds_dwordx4 (no staging registers, no ds_write), STAGES
-// tiles deep, retired by counted vmcnt waits so that loads stay in flight across the one
-// barrier per K-tile.  A wave instruction writes 1 KiB of LDS linearly (lane l -> base +
-// 16 l), i.e. 8 rows of 32 floats: rows are unpadded, and bank conflicts of the 16-byte
-// fragment reads are avoided by an XOR swizzle of the 16-byte chunk index with
-// (row >> 1) & 7, applied to each lane's SOURCE column and again on the read.
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-__device__ __forceinline__ void glds16(const float *src, float *lds_dst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                     (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
-}
-
-template <int BM, int BN, int STAGES>
-__global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvKArgs a) {
-    constexpr int WM = BM / 64, WN = BN / 64;
-    constexpr int PA = BM / 32, PB = BN / 32;  // wave instructions per K-tile, per operand
-    constexpr int LPT = PA + PB;               // loads one wave issues per K-tile
-    constexpr int STAGE = (BM + BN) * BK;      // floats per stage: A rows then B rows, 128-byte rows
-    constexpr int LDS_FLOATS = STAGES * STAGE > BM * (BN + 4) + 4 ? STAGES * STAGE : BM * (BN + 4) + 4;
-    static_assert(STAGES == 3 || STAGES == 4, "pipeline depth");
-    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
-    const int l31 = lane & 31, half = lane >> 5;
-
-    const int nt = gridDim.x, xq = nt >> 3, xr = nt & 7;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + slot;
-    const int tm = tile / a.tiles_n, tn = tile - tm * a.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int ph = blockIdx.z / a.splits, sp = blockIdx.z - ph * a.splits;
-    const int *tab = a.table + ph * PHASE_TABLE_INTS;
-    const int ntaps = tab[0], off_y = tab[1], off_x = tab[2];
-    const float *wt = a.wt + tab[3];
-    const int ktot = ntaps * a.cin;
-    const int kbeg = sp * a.ksplit;
-    const int kend = min(ktot, kbeg + a.ksplit);
-
-    // loader: this lane's row within a 32-row pass and its (swizzled) source column
-    const int r8 = lane >> 3;
-    const int lrow = 8 * wave + r8;
-    const int lcol = ((lane & 7) ^ ((lrow >> 1) & 7)) * 4;
-    int a_iy0[PA], a_ix0[PA], a_img[PA];
-    bool a_ok[PA];
-    const int hw = a.hm * a.wm;
-#pragma unroll
-    for (int p = 0; p < PA; ++p) {
-        const int m = m0 + lrow + 32 * p;
-        a_ok[p] = m < a.M;
-        const int mm = a_ok[p] ? m : 0;
-        const int n = mm / hw, r = mm - n * hw;
-        const int my = r / a.wm, mx = r - my * a.wm;
-        a_iy0[p] = my * a.in_stride;
-        a_ix0[p] = mx * a.in_stride;
-        a_img[p] = n * a.hin * a.win;
-    }
-    const float *aptr[PA], *bptr[PB];
-    int tap = kbeg / a.cin, ci0 = kbeg - tap * a.cin;
-#define GDPSO_SET_TAP(CI)                                                                                       \
-    {                                                                                                           \
-        int packed_; /* scalar load: a vector load here would make the compiler drain the loads in flight */  \
-        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(packed_) : "s"(tab + 4 + tap) : "memory"); \
-        const int dy_ = (int)(short)(packed_ & 0xffff), dx_ = packed_ >> 16;                                    \
-        _Pragma("unroll") for (int p = 0; p < PA; ++p) {                                                        \
-            const int iy = a_iy0[p] + dy_, ix = a_ix0[p] + dx_;                                                 \
-            const bool ok = a_ok[p] && (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;        \
-            aptr[p] = ok ? a.in + (size_t)(a_img[p] + iy * a.win + ix) * a.cin + (CI) + lcol                    \
-                         : g_zero_page + (CI) + lcol;                                                           \
-        }                                                                                                       \
-    }
-    // one K-tile of both operands into stage ST (wave-uniform destinations, per-lane sources)
-#define GDPSO_ISSUE(ST)                                                                                         \
-    {                                                                                                           \
-        float *dst_ = lds + (ST) * STAGE + 8 * wave * BK;                                                       \
-        _Pragma("unroll") for (int p = 0; p < PA; ++p) {                                                        \
-            glds16(aptr[p], dst_ + 32 * p * BK);                                                                \
-            aptr[p] += BK;                                                                                      \
-        }                                                                                                       \
-        _Pragma("unroll") for (int p = 0; p < PB; ++p) {                                                        \
-            glds16(bptr[p], dst_ + BM * BK + 32 * p * BK);                                                      \
-            bptr[p] += BK;                                                                                      \
-        }                                                                                                       \
-        ci0 += BK;                                                                                              \
-        if (ci0 == a.cin) {                                                                                     \
-            ci0 = 0;                                                                                            \
-            if (++tap < ntaps) GDPSO_SET_TAP(0)                                                                 \
-        }                                                                                                       \
-    }
-
-    f32x16 acc[WM][WN];
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int T = kbeg < kend ? (kend - kbeg) / BK : 0;
-    if (T > 0) {
-        GDPSO_SET_TAP(ci0)
-#pragma unroll
-        for (int p = 0; p < PB; ++p) bptr[p] = wt + (size_t)(n0 + lrow + 32 * p) * ktot + kbeg + lcol;
-#pragma unroll
-        for (int t = 0; t < STAGES - 1; ++t)
-            if (t < T) GDPSO_ISSUE(t)
-    }
-    // fragment read offsets: logical chunk 2g + half of this lane's row, swizzled like the loads
-    int foff[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) foff[g] = ((2 * g + half) ^ ((l31 >> 1) & 7)) * 4;
-    const int a_row = (wr * (BM / 2) + l31) * BK, b_row = BM * BK + (wc * (BN / 2) + l31) * BK;
-    int stage = 0;
-    for (int t = 0; t < T; ++t) {
-        // retire tile t: everything but the loads of the (at most STAGES - 2) tiles behind it
-        const int behind = min(STAGES - 2, T - 1 - t);
-        if (behind >= 2)
-            wait_vmcnt<2 * LPT>();
-        else if (behind == 1)
-            wait_vmcnt<LPT>();
-        else
-            wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();  // tile t has landed for every wave; tile t-1 is no longer being read
-        if (t + STAGES - 1 < T) {
-            const int st = stage == 0 ? STAGES - 1 : stage - 1;  // the stage tile t-1 used
-            GDPSO_ISSUE(st)
-        }
-        const float *pa = lds + stage * STAGE + a_row;
-        const float *pb = lds + stage * STAGE + b_row;
-        f32x4 av[2][WM], bv[2][WN];
-#define GDPSO_LOADFRAG(SET, G)                                                                                  \
-    {                                                                                                           \
-        _Pragma("unroll") for (int i = 0; i < WM; ++i) av[SET][i] = *(const f32x4 *)(pa + i * 32 * BK + foff[G]); \
-        _Pragma("unroll") for (int j = 0; j < WN; ++j) bv[SET][j] = *(const f32x4 *)(pb + j * 32 * BK + foff[G]); \
-    }
-        GDPSO_LOADFRAG(0, 0)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (g < 3) GDPSO_LOADFRAG((g + 1) & 1, g + 1)
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int i = 0; i < WM; ++i)
-#pragma unroll
-                    for (int j = 0; j < WN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1][i][s], bv[g & 1][j][s], acc[i][j], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x100, WM + WN, 0);
-#pragma unroll
-        for (int g = 0; g < 3; ++g) {
-            __builtin_amdgcn_sched_group_barrier(0x100, WM + WN, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * WM * WN, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * WM * WN, 0);
-        stage = stage + 1 == STAGES ? 0 : stage + 1;
-    }
-#undef GDPSO_SET_TAP
-#undef GDPSO_ISSUE
-#undef GDPSO_LOADFRAG
-    __syncthreads();  // every wave is done reading operands before the tile goes through LDS
-    conv_epilogue<BM, BN>(a, lds, LDS_FLOATS, acc, tid, m0, n0, ph, sp, nt, tile, off_y, off_x);
+    conv_epilogue<BM, BN>(a, lds, 2 * (BM + BN) * LDA, acc, tid, m0, n0, sp, tile, P);
 }
 
 // Sums the split-K slabs and applies the epilogue.  One float4 (4 channels) per thread.
@@ -532,20 +399,15 @@ struct ConvTiming {
     bool on = false;
     std::vector<hipEvent_t> events;
     size_t used = 0;
-    double flops = 0.0;
+    double flops = 0.0;     // nominal: every tap of every output pixel, padding included
+    double executed = 0.0;  // what the launches actually multiplied (padding taps of border classes skipped)
     double bytes = 0.0;  // input + weights + output (+ residual), each counted once per launch
 } g_timing;
 }  // namespace
 
-// Development switches (A/B measurements on one device).  Measured at 512 images on MI355X:
-// the register-staged kernel with the separate split-K reduce kernel is 1-3 % faster end to
-// end than the direct-to-LDS kernel and than the in-kernel (last-arriver) reduction, which
-// only pay on much longer K loops / larger grids (103 vs 100 TFLOP/s at 8192 x 2048 x 4096).
-static bool g_use_dma = [] {
-    const char *e = getenv("GDPSO_CONV_DMA");
-    return e ? e[0] != '0' : false;
-}();
-
+// Development switch (A/B measurements on one device).  Measured at 512 images on MI355X:
+// the separate split-K reduce kernel is 1-3 % faster end to end than the in-kernel
+// (last-arriver) reduction, which only pays on much longer K loops / larger grids.
 static int g_fused_max_splits = [] {
     const char *e = getenv("GDPSO_SPLITK_FUSED_MAX");
     return e ? atoi(e) : 0;
@@ -559,20 +421,26 @@ static long max_ktot(const ConvLayer &L) {
 
 // Chooses tile and split-K.  Measured on MI355X over the ResNet50 / generator shapes at 512
 // images: 64x64 tiles beat 128x128 unless the grid is several workgroups per CU deep, and
-// split-K only pays when the unsplit grid leaves CUs idle.
+// split-K only pays when the unsplit grid has fewer workgroups than CUs; then just enough
+// splits to give every CU one workgroup.
+static long m_tiles(const ConvLayer &L, int n_images, int tile) {
+    long t = 0;
+    for (int p = 0; p < L.nphase; ++p) t += ceil_div((long)n_images * L.phase[p].hm * L.phase[p].wm, tile);
+    return t;
+}
+
 int plan_conv(ConvLayer &L, int n_images, int num_cus) {
-    const long M = (long)n_images * L.hm * L.wm;
     L.tile = 64;
     if (L.cout % 128 == 0) {
-        const long t128 = (long)ceil_div(M, 128) * (L.cout / 128) * L.nphase;
+        const long t128 = m_tiles(L, n_images, 128) * (L.cout / 128);
         if (t128 >= 4L * num_cus) L.tile = 128;
     }
     if (L.cout % L.tile != 0) return fail(GDPSO_ERR_ARG, "conv: cout must be a multiple of 64");
-    const long tiles = (long)ceil_div(M, L.tile) * (L.cout / L.tile) * L.nphase;
+    const long tiles = m_tiles(L, n_images, L.tile) * (L.cout / L.tile);
     const long ktot = max_ktot(L);
     int splits = 1;
-    if (tiles * 10 < 14L * num_cus) {
-        splits = (int)std::min<long>(ceil_div(2L * num_cus, tiles), 16);
+    if (tiles < num_cus) {
+        splits = (int)std::min<long>(ceil_div((long)num_cus, tiles), 16);
         // keep at least 128 k per split so the prologue/epilogue stays amortised
         splits = (int)std::max<long>(1, std::min<long>(splits, ktot / 128));
     }
@@ -597,26 +465,30 @@ int launch_conv(const ConvLayer &L, hipStream_t stream, int n_images, const floa
                 float *out, float *splitk_ws) {
     ConvKArgs a;
     a.in = in; a.wt = L.wt; a.scale = L.scale; a.shift = L.shift; a.res = res; a.out = out;
-    const int tiles_total = ceil_div((long)n_images * L.hm * L.wm, L.tile) * (L.cout / L.tile) * L.nphase;
+    const long tiles_m = m_tiles(L, n_images, L.tile);
+    const long tiles_total = tiles_m * (L.cout / L.tile);
     // in-kernel (last-arriver) reduction up to GDPSO_SPLITK_FUSED_MAX splits (default: off)
     const bool fused_reduce = L.splits > 1 && L.splits <= g_fused_max_splits && (size_t)tiles_total * sizeof(int) <= SPLITK_COUNTER_BYTES;
     a.part = L.splits > 1 ? splitk_ws + SPLITK_COUNTER_BYTES / sizeof(float) : nullptr;
     a.counters = fused_reduce ? (int *)splitk_ws : nullptr;
     a.table = L.table;
-    a.M = n_images * L.hm * L.wm; a.hm = L.hm; a.wm = L.wm;
+    a.n_images = n_images;
+    long run = 0;
+    for (int p = 0; p < MAX_PHASES; ++p) {
+        if (p < L.nphase) run += ceil_div((long)n_images * L.phase[p].hm * L.phase[p].wm, L.tile);
+        a.tile_end[p] = p < L.nphase ? (int)run : 0x7fffffff;
+    }
     a.hin = L.hin; a.win = L.win; a.cin = L.cin;
     a.cout = L.cout; a.hout = L.hout; a.wout = L.wout;
     a.in_stride = L.in_stride; a.out_mul = L.out_mul;
     a.act = L.act; a.splits = L.splits;
-    const long ktot = max_ktot(L);
-    a.ksplit = ceil_div(ceil_div(ktot, BK), L.splits) * BK;
     a.tiles_n = L.cout / L.tile;
     a.slab = (long)n_images * L.hout * L.wout * L.cout;
     if (L.cin % BK != 0 || L.cin > MAX_CIN) return fail(GDPSO_ERR_ARG, "conv: cin must be a multiple of 32, at most 4096");
     if (L.splits > 1 && !splitk_ws) return fail(GDPSO_ERR_WORKSPACE, "conv: split-K workspace missing");
     if (a.slab * 4 >= (1L << 31)) return fail(GDPSO_ERR_ARG, "conv: output larger than 2 GiB");
-    const int tiles_m = ceil_div(a.M, L.tile);
-    dim3 grid(tiles_m * a.tiles_n, 1, L.nphase * L.splits);
+    if (tiles_total >= (1L << 31) || (long)n_images * L.hout * L.wout >= (1L << 31)) return fail(GDPSO_ERR_ARG, "conv: too many rows");
+    dim3 grid((unsigned)tiles_total, 1, L.splits);
     // With timing on, the kernel's own begin/end timestamps are attached to two events by the
     // launch itself (no extra markers on the stream, so nothing but the kernel is timed).
     const bool timed = g_timing.on && g_timing.used + 2 <= g_timing.events.size();
@@ -627,26 +499,18 @@ int launch_conv(const ConvLayer &L, hipStream_t stream, int n_images, const floa
         hipExtLaunchKernelGGL((KERNEL), grid, dim3(256), 0, stream, e0, e1, 0, a);           \
     else                                                                                     \
         hipLaunchKernelGGL((KERNEL), grid, dim3(256), 0, stream, a);
-    if (g_use_dma) {
-        if (L.tile == 128) {
-            GDPSO_LAUNCH((conv_gemm_dma_kernel<128, 128, 3>))
-        } else {
-            GDPSO_LAUNCH((conv_gemm_dma_kernel<64, 64, 4>))
-        }
+    if (L.tile == 128) {
+        GDPSO_LAUNCH((conv_gemm_kernel<128, 128>))
     } else {
-        if (L.tile == 128) {
-            GDPSO_LAUNCH((conv_gemm_kernel<128, 128>))
-        } else {
-            GDPSO_LAUNCH((conv_gemm_kernel<64, 64>))
-        }
+        GDPSO_LAUNCH((conv_gemm_kernel<64, 64>))
     }
 #undef GDPSO_LAUNCH
     if (timed) {
         g_timing.used += 2;
         g_timing.flops += L.flops_nominal * n_images;
-        double wbytes = 0.0;
-        for (int p = 0; p < L.nphase; ++p) wbytes += (double)L.phase[p].ntaps * L.cin * L.cout;
-        g_timing.bytes += 4.0 * ((double)n_images * L.hin * L.win * L.cin + wbytes + (double)a.slab * (res ? 2 : 1));
+        for (int p = 0; p < L.nphase; ++p)
+            g_timing.executed += 2.0 * n_images * L.phase[p].hm * L.phase[p].wm * (double)L.phase[p].ntaps * L.cin * L.cout;
+        g_timing.bytes += 4.0 * ((double)n_images * L.hin * L.win * L.cin + (double)L.weight_floats + (double)a.slab * (res ? 2 : 1));
     }
     if (L.splits > 1 && !fused_reduce) {
         const long quads = a.slab / 4;
@@ -670,6 +534,7 @@ extern "C" int gdpso_conv_timing_begin(int max_launches) {
     g_timing.used = 0;
     g_timing.flops = 0.0;
     g_timing.bytes = 0.0;
+    g_timing.executed = 0.0;
     g_timing.on = true;
     return GDPSO_OK;
 }
@@ -691,6 +556,7 @@ extern "C" int gdpso_conv_timing_end(double *total_ms, int *launches, double *fl
 }
 
 extern "C" double gdpso_conv_timing_bytes(void) { return gdpso::g_timing.bytes; }
+extern "C" double gdpso_conv_timing_executed_flops(void) { return gdpso::g_timing.executed; }
 
 // Times one convolution layer in isolation (development / tuning aid): random weights and
 // inputs, `reps` back-to-back launches bracketed by HIP events.  tile = 0 / splits = 0 keep

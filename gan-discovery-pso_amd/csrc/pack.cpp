@@ -1,5 +1,7 @@
 // Host-side weight repacking: PyTorch layouts -> the layouts the kernels read.
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -41,12 +43,66 @@ void fold_bn(int c, const float *bias, const float *gamma, const float *beta, co
     }
 }
 
-static bool tap_ever_in_range(int k, int stride, int pad, int n_out, int n_in) {
+// A run of consecutive output coordinates along one axis that see the same set of in-range
+// kernel offsets (the first rows of a padded convolution miss the top taps, and so on).
+struct AxisRun {
+    int o0, len;
+    std::vector<int> ks;   // kernel indices in range for every coordinate of the run
+    std::vector<int> ds;   // the input offset each of them adds
+};
+
+// `offset_of(k)` is the input coordinate minus o*stride for kernel index k.
+template <class F>
+static std::vector<AxisRun> axis_runs(int nk, int stride, int n_out, int n_in, F offset_of, bool split) {
+    std::vector<AxisRun> runs;
+    unsigned long prev = ~0ul;
     for (int o = 0; o < n_out; ++o) {
-        const int i = o * stride - pad + k;
-        if (i >= 0 && i < n_in) return true;
+        unsigned long mask = 0;
+        for (int k = 0; k < nk; ++k) {
+            const int i = o * stride + offset_of(k);
+            if (i >= 0 && i < n_in) mask |= 1ul << k;
+        }
+        if (runs.empty() || mask != prev) {
+            AxisRun r;
+            r.o0 = o;
+            r.len = 0;
+            for (int k = 0; k < nk; ++k)
+                if (mask >> k & 1) {
+                    r.ks.push_back(k);
+                    r.ds.push_back(offset_of(k));
+                }
+            runs.push_back(r);
+            prev = mask;
+        }
+        runs.back().len++;
     }
-    return false;
+    if (!split && runs.size() > 1) {  // one run with every offset that is ever in range (zeros are read for the rest)
+        AxisRun all;
+        all.o0 = 0;
+        all.len = n_out;
+        for (int k = 0; k < nk; ++k) {
+            bool any = false;
+            for (const AxisRun &r : runs)
+                for (int kk : r.ks) any |= kk == k;
+            if (any) {
+                all.ks.push_back(k);
+                all.ds.push_back(offset_of(k));
+            }
+        }
+        runs.assign(1, all);
+    }
+    return runs;
+}
+
+// GDPSO_CONV_BORDER_CLASSES=0 keeps every padded convolution in one phase (A/B measurements).
+static bool border_classes_enabled() {
+    const char *e = getenv("GDPSO_CONV_BORDER_CLASSES");
+    return e ? e[0] != '0' : true;
+}
+
+static void sort_phases_heaviest_first(ConvLayer &L) {
+    // workgroups are dispatched in phase order: long K loops first, short ones fill the tail
+    std::stable_sort(L.phase, L.phase + L.nphase, [](const ConvPhase &a, const ConvPhase &b) { return a.ntaps > b.ntaps; });
 }
 
 void make_conv(ConvLayer &L, const float *w, int cout, int cin, int kh, int kw, int stride, int pad,
@@ -58,85 +114,145 @@ void make_conv(ConvLayer &L, const float *w, int cout, int cin, int kh, int kw, 
     L.cout = cout_pad;
     L.hin = hin;
     L.win = win;
-    L.hout = L.hm = (hin + 2 * pad - kh) / stride + 1;
-    L.wout = L.wm = (win + 2 * pad - kw) / stride + 1;
+    L.hout = (hin + 2 * pad - kh) / stride + 1;
+    L.wout = (win + 2 * pad - kw) / stride + 1;
     L.in_stride = stride;
     L.out_mul = 1;
-    L.nphase = 1;
     L.act = act;
     L.flops_nominal = 2.0 * L.hout * L.wout * cout * cin * kh * kw;
-    ConvPhase &P = L.phase[0];
+    bool split = border_classes_enabled();
+    auto rows = axis_runs(kh, stride, L.hout, hin, [&](int k) { return k - pad; }, split);
+    auto cols = axis_runs(kw, stride, L.wout, win, [&](int k) { return k - pad; }, split);
+    if (rows.size() * cols.size() > (size_t)MAX_PHASES) {
+        rows = axis_runs(kh, stride, L.hout, hin, [&](int k) { return k - pad; }, false);
+        cols = axis_runs(kw, stride, L.wout, win, [&](int k) { return k - pad; }, false);
+    }
+    // weight rows hold the taps that are in range for at least one output pixel
+    std::vector<int> slot(kh * kw, -1);
     std::vector<int> live;
-    for (int ky = 0; ky < kh; ++ky)
-        for (int kx = 0; kx < kw; ++kx)
-            if (tap_ever_in_range(ky, stride, pad, L.hm, hin) && tap_ever_in_range(kx, stride, pad, L.wm, win)) {
-                P.dy[live.size()] = (int8_t)(ky - pad);
-                P.dx[live.size()] = (int8_t)(kx - pad);
-                live.push_back(ky * kw + kx);
-            }
-    P.ntaps = (int)live.size();
-    const size_t ktot = (size_t)P.ntaps * cin_pad;
+    for (const AxisRun &r : rows)
+        for (const AxisRun &c : cols)
+            for (int ky : r.ks)
+                for (int kx : c.ks)
+                    if (slot[ky * kw + kx] < 0) slot[ky * kw + kx] = 0;
+    for (int t = 0; t < kh * kw; ++t)
+        if (slot[t] == 0) {
+            slot[t] = (int)live.size();
+            live.push_back(t);
+        }
+    const size_t ktot = live.size() * (size_t)cin_pad;
     packed.assign((size_t)cout_pad * ktot, 0.f);
     for (int co = 0; co < cout; ++co)
-        for (int t = 0; t < P.ntaps; ++t)
+        for (size_t t = 0; t < live.size(); ++t)
             for (int ci = 0; ci < cin; ++ci)
-                packed[(size_t)co * ktot + (size_t)t * cin_pad + ci] = w[((size_t)co * cin + ci) * kh * kw + live[t]];
+                packed[(size_t)co * ktot + t * cin_pad + ci] = w[((size_t)co * cin + ci) * kh * kw + live[t]];
+    L.weight_floats = packed.size();
+    L.nphase = 0;
+    for (const AxisRun &r : rows)
+        for (const AxisRun &c : cols) {
+            ConvPhase &P = L.phase[L.nphase++];
+            P.off_y = r.o0;
+            P.off_x = c.o0;
+            P.hm = r.len;
+            P.wm = c.len;
+            P.in_y0 = r.o0 * stride;
+            P.in_x0 = c.o0 * stride;
+            P.wt_offset = 0;
+            P.wstride = (int)ktot;
+            P.ntaps = 0;
+            for (size_t a = 0; a < r.ks.size(); ++a)
+                for (size_t b = 0; b < c.ks.size(); ++b) {
+                    P.dy[P.ntaps] = (int8_t)r.ds[a];
+                    P.dx[P.ntaps] = (int8_t)c.ds[b];
+                    P.wtap[P.ntaps] = (int16_t)slot[r.ks[a] * kw + c.ks[b]];
+                    P.ntaps++;
+                }
+        }
+    sort_phases_heaviest_first(L);
 }
 
 // ConvTranspose2d(k=4, s=2, p=1): oy = 2*iy - 1 + ky.  Output row 2m takes (iy, ky) in
 // {(m,1), (m-1,3)}; row 2m+1 takes {(m,2), (m+1,0)}; likewise along x.  Each of the four
-// output phases is therefore a 2x2-tap convolution over the input.
+// output (sub-pixel) phases is therefore a 2x2-tap convolution over the input, and each is
+// split further into border classes where m-1 or m+1 leaves the input.
 void make_convt_k4s2p1(ConvLayer &L, const float *w, int cin, int cout, int hin, int win, int act,
                        std::vector<float> &packed) {
     std::memset(&L, 0, sizeof(L));
     L.cin = cin;
     L.cout = cout;
-    L.hin = L.hm = hin;
-    L.win = L.wm = win;
+    L.hin = hin;
+    L.win = win;
     L.hout = 2 * hin;
     L.wout = 2 * win;
     L.in_stride = 1;
     L.out_mul = 2;
-    L.nphase = 4;
     L.act = act;
     L.flops_nominal = 2.0 * L.hout * L.wout * cout * cin * 4;
     static const int d_of[2][2] = {{0, -1}, {0, 1}};
     static const int k_of[2][2] = {{1, 3}, {2, 0}};
     const size_t ktot = (size_t)4 * cin;
     packed.assign((size_t)4 * cout * ktot, 0.f);
+    L.weight_floats = packed.size();
+    const bool split = border_classes_enabled();
+    L.nphase = 0;
     for (int py = 0; py < 2; ++py)
         for (int px = 0; px < 2; ++px) {
-            const int ph = py * 2 + px;
-            ConvPhase &P = L.phase[ph];
-            P.ntaps = 4;
-            P.off_y = py;
-            P.off_x = px;
-            P.wt_offset = (long)ph * cout * ktot;
+            const long wt_offset = (long)(py * 2 + px) * cout * ktot;
             for (int ty = 0; ty < 2; ++ty)
                 for (int tx = 0; tx < 2; ++tx) {
                     const int t = ty * 2 + tx;
-                    P.dy[t] = (int8_t)d_of[py][ty];
-                    P.dx[t] = (int8_t)d_of[px][tx];
                     const int ky = k_of[py][ty], kx = k_of[px][tx];
                     for (int co = 0; co < cout; ++co)
                         for (int ci = 0; ci < cin; ++ci)
-                            packed[P.wt_offset + (size_t)co * ktot + (size_t)t * cin + ci] =
+                            packed[wt_offset + (size_t)co * ktot + (size_t)t * cin + ci] =
                                 w[(((size_t)ci * cout + co) * 4 + ky) * 4 + kx];
                 }
+            const auto rows = axis_runs(2, 1, hin, hin, [&](int t) { return d_of[py][t]; }, split);
+            const auto cols = axis_runs(2, 1, win, win, [&](int t) { return d_of[px][t]; }, split);
+            for (const AxisRun &r : rows)
+                for (const AxisRun &c : cols) {
+                    ConvPhase &P = L.phase[L.nphase++];
+                    P.off_y = 2 * r.o0 + py;
+                    P.off_x = 2 * c.o0 + px;
+                    P.hm = r.len;
+                    P.wm = c.len;
+                    P.in_y0 = r.o0;
+                    P.in_x0 = c.o0;
+                    P.wt_offset = wt_offset;
+                    P.wstride = (int)ktot;
+                    P.ntaps = 0;
+                    for (size_t a = 0; a < r.ks.size(); ++a)
+                        for (size_t b = 0; b < c.ks.size(); ++b) {
+                            P.dy[P.ntaps] = (int8_t)r.ds[a];
+                            P.dx[P.ntaps] = (int8_t)c.ds[b];
+                            P.wtap[P.ntaps] = (int16_t)(r.ks[a] * 2 + c.ks[b]);
+                            P.ntaps++;
+                        }
+                }
         }
+    sort_phases_heaviest_first(L);
 }
 
+// Device table of a layer: per phase PHASE_HDR ints {ntaps, off_y, off_x, wt_offset, hm, wm,
+// in_y0, in_x0, wstride, 0, 0, 0} followed by MAX_TAPS packed taps (dy & 0xff) | (dx & 0xff) << 8
+// | wtap << 16.
 int upload_conv(DeviceArena &arena, ConvLayer &L, const std::vector<float> &packed,
                 const std::vector<float> &scale, const std::vector<float> &shift) {
-    std::vector<int> table((size_t)L.nphase * (4 + MAX_TAPS), 0);
+    std::vector<int> table((size_t)L.nphase * (PHASE_HDR + MAX_TAPS), 0);
     for (int p = 0; p < L.nphase; ++p) {
-        int *t = table.data() + (size_t)p * (4 + MAX_TAPS);
-        t[0] = L.phase[p].ntaps;
-        t[1] = L.phase[p].off_y;
-        t[2] = L.phase[p].off_x;
-        t[3] = (int)L.phase[p].wt_offset;
-        for (int k = 0; k < L.phase[p].ntaps; ++k)
-            t[4 + k] = ((int)L.phase[p].dy[k] & 0xffff) | ((int)L.phase[p].dx[k] << 16);
+        const ConvPhase &P = L.phase[p];
+        int *t = table.data() + (size_t)p * (PHASE_HDR + MAX_TAPS);
+        t[0] = P.ntaps;
+        t[1] = P.off_y;
+        t[2] = P.off_x;
+        t[3] = (int)P.wt_offset;
+        t[4] = P.hm;
+        t[5] = P.wm;
+        t[6] = P.in_y0;
+        t[7] = P.in_x0;
+        t[8] = P.wstride;
+        for (int k = 0; k < P.ntaps; ++k)
+            t[PHASE_HDR + k] = ((int)P.dy[k] & 0xff) | (((int)P.dx[k] & 0xff) << 8) | ((int)P.wtap[k] << 16);
     }
     int rc;
     if ((rc = arena.upload(packed, &L.wt))) return rc;

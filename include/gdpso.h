@@ -258,6 +258,9 @@ int gdpso_conv_timing_end(double *total_ms, int *launches, double *flops);
 /* Algorithmic bytes of the launches timed since the last gdpso_conv_timing_begin: input, weights,
  * output and residual of every launch, each counted once. */
 double gdpso_conv_timing_bytes(void);
+/* FLOPs those launches executed: like the nominal count, minus the taps of border pixels that
+ * fall in the padding (they are not multiplied at all). */
+double gdpso_conv_timing_executed_flops(void);
 
 /* No counterpart in the reference: times one ksize x ksize convolution layer in isolation
  * on random data (allocates and frees its own buffers; a development / tuning aid).

@@ -48,7 +48,7 @@ def main():
             for tile in (64, 128):
                 if tile == 128 and cout % 128:
                     continue
-                for splits in (1, 2, 4, 8, 16):
+                for splits in (1, 2, 3, 4, 6, 8, 16):
                     if splits > 1 and cin * k * k // splits < 64:
                         continue
                     us, _, _ = probe(args.n, hin, cin, cout, k, stride, pad, tile, splits, res)
