@@ -457,6 +457,7 @@ size_t conv_splitk_bytes(const ConvLayer &L, int n_images) {
 
 // Zeroes the arrival counters; once per forward pass, ahead of the first convolution.
 int conv_splitk_prepare(hipStream_t stream, float *splitk_ws) {
+    if (g_fused_max_splits <= 0) return GDPSO_OK;  // the counters are only read by the in-kernel reduction
     GDPSO_HIP(hipMemsetAsync(splitk_ws, 0, SPLITK_COUNTER_BYTES, stream));
     return GDPSO_OK;
 }

@@ -127,46 +127,50 @@ __global__ __launch_bounds__(256) void candidate_kernel(gdpso_swarm s, int itera
 // update_global_best (util_pso.py:135-151) over the candidate records of all ranks, the
 // inertia decay (:178-179) and the early-stopping test (:186-188).  One workgroup; every
 // rank runs it on identical inputs and reaches identical decisions.
+// One thread: the decision part of update_global_best.  Returns the winning slot or -1.
+__device__ int decide_global_best(const gdpso_swarm &s, int iteration, int schedule_inertia, int early_stopping,
+                                  double tolerance) {
+    float cur = (float)s.ctrl[GDPSO_CTRL_GBEST_VAL];
+    float best = cur;
+    int best_slot = -1, best_idx = 0x7fffffff;
+    for (int k = 0; k < s.n_ranks; ++k) {
+        const double *rec = s.cand + (size_t)k * (s.d + 2);
+        const float v = (float)rec[0];
+        const int idx = (int)rec[1];
+        if (idx < 0) continue;
+        // strict improvement over the stored best; among ranks, lowest global index wins ties
+        if (v < best || (best_slot >= 0 && v == best && idx < best_idx)) {
+            best = v;
+            best_slot = k;
+            best_idx = idx;
+        }
+    }
+    int n_imp = (int)s.ctrl[GDPSO_CTRL_N_IMPROVE];
+    if (best_slot >= 0) {
+        if (isinf(cur) && cur > 0.f)
+            s.g_best_val[n_imp - 1] = best;  // the first improvement overwrites the inf
+        else
+            s.g_best_val[n_imp++] = best;
+        s.ctrl[GDPSO_CTRL_GBEST_VAL] = (double)best;
+        s.ctrl[GDPSO_CTRL_GBEST_IDX] = (double)best_idx;
+        s.ctrl[GDPSO_CTRL_N_IMPROVE] = (double)n_imp;
+    }
+    s.g_best_val_dummy[iteration - 1] = best;
+    if (iteration > 1 && schedule_inertia) s.ctrl[GDPSO_CTRL_W] = 0.99 * s.ctrl[GDPSO_CTRL_W];
+    if (iteration > 2 && n_imp > 2 && early_stopping) {
+        const float diff = fabsf(s.g_best_val[n_imp - 1] - s.g_best_val[n_imp - 2]);
+        if (diff < (float)tolerance) s.ctrl[GDPSO_CTRL_STOP_ITER] = (double)iteration;
+    }
+    s.ctrl[GDPSO_CTRL_ITERS_DONE] = (double)iteration;
+    return best_slot;
+}
+
 __global__ __launch_bounds__(64) void global_best_kernel(gdpso_swarm s, int iteration, int schedule_inertia,
                                                          int early_stopping, double tolerance) {
     __shared__ int s_take;
     if (!running(s.ctrl, iteration)) return;
     const int tid = threadIdx.x;
-    if (tid == 0) {
-        float cur = (float)s.ctrl[GDPSO_CTRL_GBEST_VAL];
-        float best = cur;
-        int best_slot = -1, best_idx = 0x7fffffff;
-        for (int k = 0; k < s.n_ranks; ++k) {
-            const double *rec = s.cand + (size_t)k * (s.d + 2);
-            const float v = (float)rec[0];
-            const int idx = (int)rec[1];
-            if (idx < 0) continue;
-            // strict improvement over the stored best; among ranks, lowest global index wins ties
-            if (v < best || (best_slot >= 0 && v == best && idx < best_idx)) {
-                best = v;
-                best_slot = k;
-                best_idx = idx;
-            }
-        }
-        int n_imp = (int)s.ctrl[GDPSO_CTRL_N_IMPROVE];
-        if (best_slot >= 0) {
-            if (isinf(cur) && cur > 0.f)
-                s.g_best_val[n_imp - 1] = best;  // the first improvement overwrites the inf
-            else
-                s.g_best_val[n_imp++] = best;
-            s.ctrl[GDPSO_CTRL_GBEST_VAL] = (double)best;
-            s.ctrl[GDPSO_CTRL_GBEST_IDX] = (double)best_idx;
-            s.ctrl[GDPSO_CTRL_N_IMPROVE] = (double)n_imp;
-        }
-        s.g_best_val_dummy[iteration - 1] = best;
-        if (iteration > 1 && schedule_inertia) s.ctrl[GDPSO_CTRL_W] = 0.99 * s.ctrl[GDPSO_CTRL_W];
-        if (iteration > 2 && n_imp > 2 && early_stopping) {
-            const float diff = fabsf(s.g_best_val[n_imp - 1] - s.g_best_val[n_imp - 2]);
-            if (diff < (float)tolerance) s.ctrl[GDPSO_CTRL_STOP_ITER] = (double)iteration;
-        }
-        s.ctrl[GDPSO_CTRL_ITERS_DONE] = (double)iteration;
-        s_take = best_slot;
-    }
+    if (tid == 0) s_take = decide_global_best(s, iteration, schedule_inertia, early_stopping, tolerance);
     __syncthreads();
     const int slot = s_take;
     if (slot >= 0) {
@@ -201,11 +205,8 @@ __device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {
 //   best_soci = (w_soci * r2) * (p_best_pos - pos)      (r2 pairs with the PERSONAL best)
 //   vel = (inertia + best_soci) + best_cogn ;  pos = pos + vel
 // r1, r2 are scalars per particle.  One thread per (particle, dimension) element.
-__global__ __launch_bounds__(256) void move_kernel(gdpso_swarm s, int iteration, double w_cogn, double w_soci,
-                                                   const double *__restrict__ rnd, uint64_t seed, int f32_terms) {
-    if (!running(s.ctrl, iteration)) return;
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (long)s.n * s.d) return;
+__device__ __forceinline__ void move_element(const gdpso_swarm &s, int iteration, long e, double w, double w_cogn,
+                                             double w_soci, const double *__restrict__ rnd, uint64_t seed, int f32_terms) {
     const int p = (int)(e / s.d), k = (int)(e - (long)p * s.d);
     double r1, r2;
     if (rnd) {
@@ -217,7 +218,6 @@ __global__ __launch_bounds__(256) void move_kernel(gdpso_swarm s, int iteration,
         r1 = u53(o[0], o[1]);
         r2 = u53(o[2], o[3]);
     }
-    const double w = s.ctrl[GDPSO_CTRL_W];
     const double x = s.pos[e], v = s.vel[e];
     const double inertia = w * v;
     const double c1 = w_cogn * r1;
@@ -242,14 +242,94 @@ __global__ __launch_bounds__(256) void move_kernel(gdpso_swarm s, int iteration,
     if (s.hist_vel) s.hist_vel[h] = nv;
 }
 
+__global__ __launch_bounds__(256) void move_kernel(gdpso_swarm s, int iteration, double w_cogn, double w_soci,
+                                                   const double *__restrict__ rnd, uint64_t seed, int f32_terms) {
+    if (!running(s.ctrl, iteration)) return;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)s.n * s.d) return;
+    move_element(s, iteration, e, s.ctrl[GDPSO_CTRL_W], w_cogn, w_soci, rnd, seed, f32_terms);
+}
+
+// The four phases above for a swarm small enough for one workgroup (single process): personal
+// bests, this swarm's candidate, the global-best decision and the move, separated by
+// workgroup barriers instead of kernel boundaries.  Same device functions, same results.
+constexpr int SMALL_THREADS = 1024;
+constexpr int SMALL_MAX_N = 4096;
+__global__ __launch_bounds__(SMALL_THREADS) void swarm_step_small_kernel(gdpso_swarm s, int iteration, int schedule_inertia,
+                                                                         int early_stopping, double tolerance, double w_cogn,
+                                                                         double w_soci, const double *__restrict__ rnd,
+                                                                         uint64_t seed, int f32_terms) {
+    __shared__ unsigned char s_better[SMALL_MAX_N];
+    __shared__ BestRec s_best[SMALL_THREADS / 64];
+    __shared__ int s_take;
+    if (!running(s.ctrl, iteration)) return;
+    const int tid = threadIdx.x;
+    // update_personal_best
+    BestRec r;
+    r.val = INFINITY;
+    r.idx = 0x7fffffff;
+    for (int p = tid; p < s.n; p += SMALL_THREADS) {
+        const float f = s.fitness[p];
+        float pb = s.pbest_val[p];
+        const bool better = f < pb;
+        if (better) {
+            pb = f;
+            s.pbest_val[p] = f;
+        }
+        s_better[p] = better;
+        BestRec c;
+        c.val = pb;
+        c.idx = s.first_index + p;
+        r = better_of(r, c);
+    }
+    r = wave_best(r);
+    if ((tid & 63) == 0) s_best[tid >> 6] = r;
+    __syncthreads();
+    const long nd = (long)s.n * s.d;
+    for (long e = tid; e < nd; e += SMALL_THREADS)
+        if (s_better[e / s.d]) s.pbest_pos[e] = s.pos[e];
+    r = s_best[0];
+#pragma unroll
+    for (int w = 1; w < SMALL_THREADS / 64; ++w) r = better_of(r, s_best[w]);
+    __threadfence_block();
+    __syncthreads();
+    // this swarm's candidate record
+    double *rec = s.cand;
+    const bool have = r.idx != 0x7fffffff && r.val < INFINITY;
+    if (tid == 0) {
+        rec[0] = have ? (double)r.val : (double)INFINITY;
+        rec[1] = have ? (double)r.idx : -1.0;
+    }
+    for (int k = tid; k < s.d; k += SMALL_THREADS) rec[2 + k] = have ? s.pbest_pos[(size_t)(r.idx - s.first_index) * s.d + k] : 0.0;
+    __threadfence_block();
+    __syncthreads();
+    // update_global_best, inertia decay, early-stopping test
+    if (tid == 0) s_take = decide_global_best(s, iteration, schedule_inertia, early_stopping, tolerance);
+    __syncthreads();
+    if (s_take >= 0)
+        for (int k = tid; k < s.d; k += SMALL_THREADS) s.gbest_pos[k] = rec[2 + k];
+    __threadfence_block();
+    __syncthreads();
+    // move_particles
+    const double w = s.ctrl[GDPSO_CTRL_W];
+    for (long e = tid; e < nd; e += SMALL_THREADS) move_element(s, iteration, e, w, w_cogn, w_soci, rnd, seed, f32_terms);
+}
+
 // Swarm.mse (util_pso.py:76-86): mean Euclidean distance over unordered pairs.  Tile of
 // 64 x 64 pairs per workgroup (upper triangle only), float64 throughout; per-workgroup sums
 // are combined in a fixed order by the finishing kernel, so the result is reproducible.
-// DT particles per tile side: the largest power of two in [8, 64] whose two tiles fit 48 KiB.
+// DT particles per tile side: a power of two in [8, 64] whose two tiles fit 48 KiB, smaller
+// for small swarms (the tile side fixes the summation order, so it depends on n and d only).
 constexpr int DT_MIN = 8;
-static int dist_tile_side(int d) {
+static int dist_tile_side(int d, int n) {
     int dt = 64;
     while (dt > DT_MIN && (size_t)2 * dt * d * sizeof(double) > 48 * 1024) dt >>= 1;
+    // small swarms: smaller tiles until there are enough workgroups to spread over the chip
+    while (dt > 16) {
+        const long t = (n + dt - 1) / dt;
+        if (t * (t + 1) / 2 >= 128) break;
+        dt >>= 1;
+    }
     return dt;
 }
 __global__ __launch_bounds__(256) void pair_dist_kernel(const double *__restrict__ pos, int n, int d, int DT, int tiles,
@@ -383,7 +463,7 @@ extern "C" int gdpso_swarm_mean_distance(const gdpso_swarm *s, void *stream, int
     GDPSO_REQUIRE(s->mean_dist && pos_all, "swarm_mean_distance: null buffer");
     GDPSO_REQUIRE(iteration >= 1 && iteration <= s->max_iter, "swarm_mean_distance: iteration out of range");
     GDPSO_REQUIRE(n_all >= 2, "swarm_mean_distance: needs at least two particles");
-    const int DT = dist_tile_side(s->d);
+    const int DT = dist_tile_side(s->d, n_all);
     GDPSO_REQUIRE((size_t)2 * DT * s->d * sizeof(double) <= 64 * 1024, "swarm_mean_distance: dim_space too large");
     GDPSO_REQUIRE(gdpso_swarm_scratch_bytes(std::max(n_all, s->n)) <= s->scratch_bytes, "swarm_mean_distance: scratch too small");
     const int tiles = ceil_div(n_all, DT);
@@ -415,10 +495,17 @@ extern "C" int gdpso_swarm_iterate(const gdpso_swarm *s, const gdpso_generator *
                                          r->eps, r->target ? r->mse : nullptr, r->w_ass, r->w_rec, r->workspace,
                                          r->workspace_bytes)))
             return rc;
-        if ((rc = gdpso_swarm_local_best(s, stream, i, 0))) return rc;
-        if ((rc = gdpso_swarm_global_best(s, stream, i, r->schedule_inertia, r->early_stopping, r->tolerance))) return rc;
         const double *rnd = r->rand ? r->rand + (size_t)(i - 1) * s->n * 2 : nullptr;
-        if ((rc = gdpso_swarm_move(s, stream, i, r->w_cogn, r->w_soci, rnd, r->seed, r->f32_first_move))) return rc;
+        if (s->n <= SMALL_MAX_N && (long)s->n * s->d <= 64L * SMALL_THREADS) {
+            hipLaunchKernelGGL(swarm_step_small_kernel, dim3(1), dim3(SMALL_THREADS), 0, (hipStream_t)stream, *s, i,
+                               r->schedule_inertia, r->early_stopping, r->tolerance, r->w_cogn, r->w_soci, rnd, r->seed,
+                               (r->f32_first_move && i == 1) ? 1 : 0);
+            GDPSO_HIP(hipGetLastError());
+        } else {
+            if ((rc = gdpso_swarm_local_best(s, stream, i, 0))) return rc;
+            if ((rc = gdpso_swarm_global_best(s, stream, i, r->schedule_inertia, r->early_stopping, r->tolerance))) return rc;
+            if ((rc = gdpso_swarm_move(s, stream, i, r->w_cogn, r->w_soci, rnd, r->seed, r->f32_first_move))) return rc;
+        }
         if (r->diagnostics && s->mean_dist && s->n >= 2)
             if ((rc = gdpso_swarm_mean_distance(s, stream, i, s->pos, s->n))) return rc;
     }
