@@ -39,7 +39,6 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 using global_f32x4_ptr = const __attribute__((address_space(1))) f32x4 *;
 
 constexpr int BK = 32;
-constexpr int LDA = BK + 4;  // 144-byte rows: ds_read_b128 of 16 consecutive rows is conflict-free
 constexpr int PHASE_TABLE_INTS = PHASE_HDR + MAX_TAPS;  // header (see upload_conv) + packed taps
 
 struct ConvKArgs {
@@ -82,31 +81,15 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 // Epilogue shared by the convolution kernels.  `lds` is the workgroup's whole LDS array
 // (lds_floats long); every operand read from it must have been retired by a barrier.
+// The tile has been laid out row-major in LDS ([BM][BN + 4], starting at `lds`) and a barrier
+// has passed; it is written with 16-byte stores: one wave instruction covers whole 256/512-byte
+// row segments, and the residual is read the same way.
 template <int BM, int BN>
-__device__ __forceinline__ void conv_epilogue(const ConvKArgs &a, float *lds, int lds_floats,
-                                              f32x16 (&acc)[BM / 64][BN / 64], int tid, int m0, int n0, int sp, int tile,
-                                              const PhaseInfo &P) {
-    constexpr int WM = BM / 64, WN = BN / 64;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int l31 = lane & 31, half = lane >> 5;
+__device__ __forceinline__ void conv_store_tile(const ConvKArgs &a, float *lds, int lds_floats, int tid, int m0, int n0,
+                                                int sp, int tile, const PhaseInfo &P) {
     const int hw = P.hm * P.wm;
-    // Epilogue through LDS.  Accumulator register r of lane l is
-    // C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]; the tile is first laid out row-major
-    // in LDS (the K loop's last barrier has retired every operand read), then written with
-    // 16-byte stores: one wave instruction covers whole 256/512-byte row segments, and the
-    // residual is read the same way.
     constexpr int LDC = BN + 4;
-    
     float *sC = lds;
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                sC[(wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDC + wc * (BN / 2) + j * 32 + l31] = acc[i][j][r];
-    __syncthreads();
     constexpr int C4 = BN / 4;     // float4 per tile row
     constexpr int RPP = 256 / C4;  // tile rows per pass
     constexpr int PASSES = BM / RPP;
@@ -194,16 +177,26 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs &a, float *lds, in
     }
 }
 
-template <int BM, int BN>
+// BM x BN output tile, K-tiles of BKT floats.  KW = 1: the four waves form a 2 x 2 grid over the
+// tile.  KW = 2 (BM = 32): two waves side by side cover the tile and the other two take the
+// second half of every K-tile; the two halves are added through LDS before the epilogue.  That
+// shape doubles the number of workgroups of a small-M layer without split-K slabs.
+template <int BM, int BN, int BKT, int KW>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKArgs a) {
-    constexpr int WM = BM / 64, WN = BN / 64;  // 32x32 MFMA blocks per wave, per dimension
-    constexpr int PA = BM / 32, PB = BN / 32;  // loader passes (32 rows x 32 floats per pass)
-    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDA];
+    static_assert(BKT / KW == 32, "every wave consumes 32 k per K-tile");
+    static_assert(KW == 1 || BM == 32, "the K-split layout is for 32-row tiles");
+    constexpr int LDA = BKT + 4;  // 144- or 272-byte rows: ds_read_b128 of consecutive rows is conflict-free
+    constexpr int WM = KW == 1 ? BM / 64 : 1, WN = KW == 1 ? BN / 64 : BN / 64;  // 32x32 MFMA blocks per wave
+    constexpr int RP = 256 / (BKT / 4);        // rows covered by one loader pass
+    constexpr int PA = BM / RP, PB = BN / RP;  // loader passes
+    constexpr int LDS_FLOATS = 2 * (BM + BN) * LDA;
+    static_assert(LDS_FLOATS >= BM * (BN + 4) + 4, "the output tile is staged in the operand buffers");
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     float *sA = lds;
     float *sB = lds + 2 * BM * LDA;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = KW == 1 ? wave >> 1 : 0, wc = wave & 1, kh = KW == 1 ? 0 : wave >> 1;
     const int l31 = lane & 31, half = lane >> 5;
 
     // Workgroups b and b+8 share an XCD (and its L2): give each XCD a contiguous run of
@@ -233,18 +226,18 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKArgs a) {
     const int in_y0 = tab[6], in_x0 = tab[7], wstride = tab[8];
     const float *wt = a.wt + tab[3];
     const int ktot = ntaps * a.cin;
-    const int ksplit = ((ktot / BK + a.splits - 1) / a.splits) * BK;  // this phase's K range per split
+    const int ksplit = ((ktot / BKT + a.splits - 1) / a.splits) * BKT;  // this phase's K range per split
     const int kbeg = sp * ksplit;
     const int kend = min(ktot, kbeg + ksplit);
 
-    // loader coordinates: 8 threads x 16 B cover one 32-float row
-    const int lrow = tid >> 3, lcol = (tid & 7) * 4;
+    // loader coordinates: BKT/4 threads x 16 B cover one row of a K-tile
+    const int lrow = tid / (BKT / 4), lcol = (tid % (BKT / 4)) * 4;
     int a_iy0[PA], a_ix0[PA], a_img[PA];
     bool a_ok[PA];
     const int hw = P.hm * P.wm;
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
-        const int m = m0 + lrow + 32 * p;
+        const int m = m0 + lrow + RP * p;
         a_ok[p] = m < P.M;
         const int mm = a_ok[p] ? m : 0;
         const int n = mm / hw, r = mm - n * hw;
@@ -261,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKArgs a) {
     const float *aptr[PA], *bptr[PB];
     const float *brow[PB];
 #pragma unroll
-    for (int p = 0; p < PB; ++p) brow[p] = wt + (size_t)(n0 + lrow + 32 * p) * wstride + lcol;
+    for (int p = 0; p < PB; ++p) brow[p] = wt + (size_t)(n0 + lrow + RP * p) * wstride + lcol;
     int tap = kbeg / a.cin, ci0 = kbeg - tap * a.cin;
 #define GDPSO_SET_TAP(CI)                                                                                       \
     {                                                                                                           \
@@ -284,13 +277,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKArgs a) {
     {                                                                                                           \
         _Pragma("unroll") for (int p = 0; p < PA; ++p) {                                                        \
             ra[p] = *(global_f32x4_ptr)aptr[p];                                                                  \
-            aptr[p] += BK;                                                                                      \
+            aptr[p] += BKT;                                                                                     \
         }                                                                                                       \
         _Pragma("unroll") for (int p = 0; p < PB; ++p) {                                                        \
             rb[p] = *(global_f32x4_ptr)bptr[p];                                                                  \
-            bptr[p] += BK;                                                                                      \
+            bptr[p] += BKT;                                                                                     \
         }                                                                                                       \
-        ci0 += BK;                                                                                              \
+        ci0 += BKT;                                                                                             \
         if (ci0 == a.cin) {                                                                                     \
             ci0 = 0;                                                                                            \
             if (++tap < ntaps) GDPSO_SET_TAP(0)                                                                 \
@@ -299,9 +292,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKArgs a) {
 #define GDPSO_SSTORE(BUF)                                                                                       \
     {                                                                                                           \
         _Pragma("unroll") for (int p = 0; p < PA; ++p)                                                          \
-            *(f32x4 *)&sA[(BUF) * BM * LDA + (lrow + 32 * p) * LDA + lcol] = ra[p];                             \
+            *(f32x4 *)&sA[(BUF) * BM * LDA + (lrow + RP * p) * LDA + lcol] = ra[p];                             \
         _Pragma("unroll") for (int p = 0; p < PB; ++p)                                                          \
-            *(f32x4 *)&sB[(BUF) * BN * LDA + (lrow + 32 * p) * LDA + lcol] = rb[p];                             \
+            *(f32x4 *)&sB[(BUF) * BN * LDA + (lrow + RP * p) * LDA + lcol] = rb[p];                             \
     }
     // Operand fragments of MFMA group G (8 k's) into register set SET.
 #define GDPSO_LOADFRAG(SET, G)                                                                                  \
@@ -325,11 +318,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKArgs a) {
     }
     __syncthreads();
     int buf = 0;
-    for (int kt = kbeg; kt < kend; kt += BK) {
-        const bool more = kt + BK < kend;
+    for (int kt = kbeg; kt < kend; kt += BKT) {
+        const bool more = kt + BKT < kend;
         if (more) GDPSO_GLOAD()
-        const float *pa = sA + buf * BM * LDA + (wr * (BM / 2) + l31) * LDA + half * 4;
-        const float *pb = sB + buf * BN * LDA + (wc * (BN / 2) + l31) * LDA + half * 4;
+        const float *pa = sA + buf * BM * LDA + (wr * (BM / 2) + l31) * LDA + half * 4 + kh * 32;
+        const float *pb = sB + buf * BN * LDA + (wc * (BN / 2) + l31) * LDA + half * 4 + kh * 32;
         // Within a K-tile the 32 k's are consumed in a permuted order: MFMA step s of group g
         // takes k = 8g + 4*half + s from both operands, so each lane's four steps are one
         // 16-byte LDS read.  The sum over k is the same set of products.  The fragments of
@@ -364,7 +357,34 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKArgs a) {
 #undef GDPSO_SSTORE
 #undef GDPSO_LOADFRAG
 
-    conv_epilogue<BM, BN>(a, lds, 2 * (BM + BN) * LDA, acc, tid, m0, n0, sp, tile, P);
+    // Epilogue through LDS.  Accumulator register r of lane l is
+    // C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]; the tile is first laid out row-major
+    // in LDS (the K loop's last barrier has retired every operand read).
+    constexpr int LDC = BN + 4;
+    float *sC = lds;
+    if (KW == 1 || kh == 1) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    sC[(wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDC + wc * (BN / 2) + j * 32 + l31] = acc[i][j][r];
+    }
+    if (KW == 2) {  // first K half + second K half, always in that order
+        __syncthreads();
+        if (kh == 0) {
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float *c = &sC[((r & 3) + 8 * (r >> 2) + 4 * half) * LDC + wc * (BN / 2) + j * 32 + l31];
+                    *c = acc[0][j][r] + *c;
+                }
+        }
+    }
+    __syncthreads();
+    conv_store_tile<BM, BN>(a, lds, LDS_FLOATS, tid, m0, n0, sp, tile, P);
 }
 
 // Sums the split-K slabs and applies the epilogue.  One float4 (4 channels) per thread.
@@ -408,6 +428,11 @@ struct ConvTiming {
 // Development switch (A/B measurements on one device).  Measured at 512 images on MI355X:
 // the separate split-K reduce kernel is 1-3 % faster end to end than the in-kernel
 // (last-arriver) reduction, which only pays on much longer K loops / larger grids.
+static bool g_allow_tile32 = [] {
+    const char *e = getenv("GDPSO_CONV_TILE32");
+    return e ? e[0] != '0' : true;
+}();
+
 static int g_fused_max_splits = [] {
     const char *e = getenv("GDPSO_SPLITK_FUSED_MAX");
     return e ? atoi(e) : 0;
@@ -423,9 +448,14 @@ static long max_ktot(const ConvLayer &L) {
 // images: 64x64 tiles beat 128x128 unless the grid is several workgroups per CU deep, and
 // split-K only pays when the unsplit grid has fewer workgroups than CUs; then just enough
 // splits to give every CU one workgroup.
+// L.tile names the kernel shape: 128 -> 128x128, 64 -> 64x64, 32 -> 32 rows x 64 columns with the
+// K-tile split over wave pairs.
+static int tile_bm(int tile) { return tile; }
+static int tile_bn(int tile) { return tile == 32 ? 64 : tile; }
+
 static long m_tiles(const ConvLayer &L, int n_images, int tile) {
     long t = 0;
-    for (int p = 0; p < L.nphase; ++p) t += ceil_div((long)n_images * L.phase[p].hm * L.phase[p].wm, tile);
+    for (int p = 0; p < L.nphase; ++p) t += ceil_div((long)n_images * L.phase[p].hm * L.phase[p].wm, tile_bm(tile));
     return t;
 }
 
@@ -436,7 +466,10 @@ int plan_conv(ConvLayer &L, int n_images, int num_cus) {
         if (t128 >= 4L * num_cus) L.tile = 128;
     }
     if (L.cout % L.tile != 0) return fail(GDPSO_ERR_ARG, "conv: cout must be a multiple of 64");
-    const long tiles = m_tiles(L, n_images, L.tile) * (L.cout / L.tile);
+    // at most one 64x64 tile per CU: 32-row tiles double the workgroups without slabs (measured:
+    // a gain up to 256 tiles, a loss at 392)
+    if (L.tile == 64 && g_allow_tile32 && L.cin % 64 == 0 && m_tiles(L, n_images, 64) * (L.cout / 64) <= (long)num_cus) L.tile = 32;
+    const long tiles = m_tiles(L, n_images, L.tile) * (L.cout / tile_bn(L.tile));
     const long ktot = max_ktot(L);
     int splits = 1;
     if (tiles < num_cus) {
@@ -467,7 +500,7 @@ int launch_conv(const ConvLayer &L, hipStream_t stream, int n_images, const floa
     ConvKArgs a;
     a.in = in; a.wt = L.wt; a.scale = L.scale; a.shift = L.shift; a.res = res; a.out = out;
     const long tiles_m = m_tiles(L, n_images, L.tile);
-    const long tiles_total = tiles_m * (L.cout / L.tile);
+    const long tiles_total = tiles_m * (L.cout / tile_bn(L.tile));
     // in-kernel (last-arriver) reduction up to GDPSO_SPLITK_FUSED_MAX splits (default: off)
     const bool fused_reduce = L.splits > 1 && L.splits <= g_fused_max_splits && (size_t)tiles_total * sizeof(int) <= SPLITK_COUNTER_BYTES;
     a.part = L.splits > 1 ? splitk_ws + SPLITK_COUNTER_BYTES / sizeof(float) : nullptr;
@@ -476,14 +509,14 @@ int launch_conv(const ConvLayer &L, hipStream_t stream, int n_images, const floa
     a.n_images = n_images;
     long run = 0;
     for (int p = 0; p < MAX_PHASES; ++p) {
-        if (p < L.nphase) run += ceil_div((long)n_images * L.phase[p].hm * L.phase[p].wm, L.tile);
+        if (p < L.nphase) run += ceil_div((long)n_images * L.phase[p].hm * L.phase[p].wm, tile_bm(L.tile));
         a.tile_end[p] = p < L.nphase ? (int)run : 0x7fffffff;
     }
     a.hin = L.hin; a.win = L.win; a.cin = L.cin;
     a.cout = L.cout; a.hout = L.hout; a.wout = L.wout;
     a.in_stride = L.in_stride; a.out_mul = L.out_mul;
     a.act = L.act; a.splits = L.splits;
-    a.tiles_n = L.cout / L.tile;
+    a.tiles_n = L.cout / tile_bn(L.tile);
     a.slab = (long)n_images * L.hout * L.wout * L.cout;
     if (L.cin % BK != 0 || L.cin > MAX_CIN) return fail(GDPSO_ERR_ARG, "conv: cin must be a multiple of 32, at most 4096");
     if (L.splits > 1 && !splitk_ws) return fail(GDPSO_ERR_WORKSPACE, "conv: split-K workspace missing");
@@ -500,10 +533,13 @@ int launch_conv(const ConvLayer &L, hipStream_t stream, int n_images, const floa
         hipExtLaunchKernelGGL((KERNEL), grid, dim3(256), 0, stream, e0, e1, 0, a);           \
     else                                                                                     \
         hipLaunchKernelGGL((KERNEL), grid, dim3(256), 0, stream, a);
+    if (L.tile == 32 && L.cin % 64 != 0) return fail(GDPSO_ERR_ARG, "conv: the 32-row tile needs cin to be a multiple of 64");
     if (L.tile == 128) {
-        GDPSO_LAUNCH((conv_gemm_kernel<128, 128>))
+        GDPSO_LAUNCH((conv_gemm_kernel<128, 128, 32, 1>))
+    } else if (L.tile == 64) {
+        GDPSO_LAUNCH((conv_gemm_kernel<64, 64, 32, 1>))
     } else {
-        GDPSO_LAUNCH((conv_gemm_kernel<64, 64>))
+        GDPSO_LAUNCH((conv_gemm_kernel<32, 64, 64, 2>))
     }
 #undef GDPSO_LAUNCH
     if (timed) {
@@ -566,7 +602,7 @@ extern "C" int gdpso_conv_probe(int n_images, int hin, int cin, int cout, int ks
                                 int splits, int with_res, int reps, double *avg_us, int *tile_used, int *splits_used) {
     using namespace gdpso;
     GDPSO_REQUIRE(n_images > 0 && hin > 0 && cin % 32 == 0 && cout % 64 == 0 && reps > 0 && avg_us, "conv_probe: bad argument");
-    GDPSO_REQUIRE(tile == 0 || tile == 64 || (tile == 128 && cout % 128 == 0), "conv_probe: bad tile");
+    GDPSO_REQUIRE(tile == 0 || tile == 64 || (tile == 32 && cin % 64 == 0) || (tile == 128 && cout % 128 == 0), "conv_probe: bad tile");
     std::vector<float> w((size_t)cout * cin * ksize * ksize), packed, sc(cout, 1.f), sh(cout, 0.1f);
     uint32_t st = 12345u;
     auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 65536.f - 0.5f; };
