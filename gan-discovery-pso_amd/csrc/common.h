@@ -79,6 +79,9 @@ int conv_splitk_prepare(hipStream_t stream, float *splitk_ws);
 int launch_conv(const ConvLayer &L, hipStream_t stream, int n_images, const float *in, const float *res,
                 float *out, float *splitk_ws);
 
+int launch_conv_pair(const ConvLayer &La, const ConvLayer &Lb, hipStream_t stream, int n_images, const float *in,
+                     float *out_a, float *out_b, float *splitk_ws);
+
 // host-side helpers (pack.cpp)
 struct DeviceArena {
     std::vector<void *> blocks;

@@ -182,7 +182,7 @@ __device__ __forceinline__ void conv_store_tile(const ConvKArgs &a, float *lds, 
 // second half of every K-tile; the two halves are added through LDS before the epilogue.  That
 // shape doubles the number of workgroups of a small-M layer without split-K slabs.
 template <int BM, int BN, int BKT, int KW>
-__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKArgs a) {
+__device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, const int nt, float *lds) {
     static_assert(BKT / KW == 32, "every wave consumes 32 k per K-tile");
     static_assert(KW == 1 || BM == 32, "the K-split layout is for 32-row tiles");
     constexpr int LDA = BKT + 4;  // 144- or 272-byte rows: ds_read_b128 of consecutive rows is conflict-free
@@ -191,7 +191,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKArgs a) {
     constexpr int PA = BM / RP, PB = BN / RP;  // loader passes
     constexpr int LDS_FLOATS = 2 * (BM + BN) * LDA;
     static_assert(LDS_FLOATS >= BM * (BN + 4) + 4, "the output tile is staged in the operand buffers");
-    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     float *sA = lds;
     float *sB = lds + 2 * BM * LDA;
 
@@ -201,8 +200,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKArgs a) {
 
     // Workgroups b and b+8 share an XCD (and its L2): give each XCD a contiguous run of
     // tiles, so tiles that share input rows or weight columns hit the same L2.
-    const int nt = gridDim.x, xq = nt >> 3, xr = nt & 7;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int xq = nt >> 3, xr = nt & 7;
+    const int xcd = bx & 7, slot = bx >> 3;
     const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + slot;
     const int tmg = tile / a.tiles_n, tn = tile - tmg * a.tiles_n;
     // phase of this M-tile: the last one whose predecessors end at or before it
@@ -387,6 +386,29 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKArgs a) {
     conv_store_tile<BM, BN>(a, lds, LDS_FLOATS, tid, m0, n0, sp, tile, P);
 }
 
+template <int BM, int BN, int BKT, int KW>
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * (BKT + 4)];
+    conv_tile<BM, BN, BKT, KW>(a, blockIdx.x, gridDim.x, lds);
+}
+
+// Two independent layers in one grid (same tile shape, no split-K): the first tiles_a_pad
+// workgroups (a multiple of 8, so that both layers see workgroup index & 7 == XCD) belong to
+// layer a, the rest to layer b.  Used for identity_downsample + conv1 of a bottleneck block,
+// which read the same input: one launch, one fill and drain, and the tail of one layer overlaps
+// the other.
+template <int BM, int BN, int BKT, int KW>
+__global__ __launch_bounds__(256, 2) void conv_gemm_pair_kernel(const ConvKArgs a, const ConvKArgs b, int tiles_a,
+                                                                int tiles_a_pad) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * (BKT + 4)];
+    // two copies of the tile code, each reading its own kernel arguments straight from SGPRs
+    if ((int)blockIdx.x < tiles_a_pad) {
+        if ((int)blockIdx.x < tiles_a) conv_tile<BM, BN, BKT, KW>(a, blockIdx.x, tiles_a, lds);
+    } else {
+        conv_tile<BM, BN, BKT, KW>(b, blockIdx.x - tiles_a_pad, (int)gridDim.x - tiles_a_pad, lds);
+    }
+}
+
 // Sums the split-K slabs and applies the epilogue.  One float4 (4 channels) per thread.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ part, int splits, long slab,
                                                             int cout, const float *__restrict__ scale,
@@ -430,6 +452,11 @@ struct ConvTiming {
 // (last-arriver) reduction, which only pays on much longer K loops / larger grids.
 static bool g_allow_tile32 = [] {
     const char *e = getenv("GDPSO_CONV_TILE32");
+    return e ? e[0] != '0' : true;
+}();
+
+static bool g_pair_launch = [] {
+    const char *e = getenv("GDPSO_CONV_PAIR");
     return e ? e[0] != '0' : true;
 }();
 
@@ -495,16 +522,16 @@ int conv_splitk_prepare(hipStream_t stream, float *splitk_ws) {
     return GDPSO_OK;
 }
 
-int launch_conv(const ConvLayer &L, hipStream_t stream, int n_images, const float *in, const float *res,
-                float *out, float *splitk_ws) {
-    ConvKArgs a;
+// Fills the kernel arguments of one layer; returns its number of workgroups per split through *tiles.
+static int conv_args(const ConvLayer &L, int n_images, const float *in, const float *res, float *out, float *splitk_ws,
+                     ConvKArgs &a, long *tiles, bool *fused_reduce) {
     a.in = in; a.wt = L.wt; a.scale = L.scale; a.shift = L.shift; a.res = res; a.out = out;
     const long tiles_m = m_tiles(L, n_images, L.tile);
     const long tiles_total = tiles_m * (L.cout / tile_bn(L.tile));
     // in-kernel (last-arriver) reduction up to GDPSO_SPLITK_FUSED_MAX splits (default: off)
-    const bool fused_reduce = L.splits > 1 && L.splits <= g_fused_max_splits && (size_t)tiles_total * sizeof(int) <= SPLITK_COUNTER_BYTES;
+    *fused_reduce = L.splits > 1 && L.splits <= g_fused_max_splits && (size_t)tiles_total * sizeof(int) <= SPLITK_COUNTER_BYTES;
     a.part = L.splits > 1 ? splitk_ws + SPLITK_COUNTER_BYTES / sizeof(float) : nullptr;
-    a.counters = fused_reduce ? (int *)splitk_ws : nullptr;
+    a.counters = *fused_reduce ? (int *)splitk_ws : nullptr;
     a.table = L.table;
     a.n_images = n_images;
     long run = 0;
@@ -521,7 +548,26 @@ int launch_conv(const ConvLayer &L, hipStream_t stream, int n_images, const floa
     if (L.cin % BK != 0 || L.cin > MAX_CIN) return fail(GDPSO_ERR_ARG, "conv: cin must be a multiple of 32, at most 4096");
     if (L.splits > 1 && !splitk_ws) return fail(GDPSO_ERR_WORKSPACE, "conv: split-K workspace missing");
     if (a.slab * 4 >= (1L << 31)) return fail(GDPSO_ERR_ARG, "conv: output larger than 2 GiB");
-    if (tiles_total >= (1L << 31) || (long)n_images * L.hout * L.wout >= (1L << 31)) return fail(GDPSO_ERR_ARG, "conv: too many rows");
+    if (tiles_total >= (1L << 30) || (long)n_images * L.hout * L.wout >= (1L << 31)) return fail(GDPSO_ERR_ARG, "conv: too many rows");
+    if (L.tile == 32 && L.cin % 64 != 0) return fail(GDPSO_ERR_ARG, "conv: the 32-row tile needs cin to be a multiple of 64");
+    *tiles = tiles_total;
+    return GDPSO_OK;
+}
+
+static void conv_account(const ConvLayer &L, int n_images, const ConvKArgs &a, bool has_res) {
+    g_timing.flops += L.flops_nominal * n_images;
+    for (int p = 0; p < L.nphase; ++p)
+        g_timing.executed += 2.0 * n_images * L.phase[p].hm * L.phase[p].wm * (double)L.phase[p].ntaps * L.cin * L.cout;
+    g_timing.bytes += 4.0 * ((double)n_images * L.hin * L.win * L.cin + (double)L.weight_floats + (double)a.slab * (has_res ? 2 : 1));
+}
+
+int launch_conv(const ConvLayer &L, hipStream_t stream, int n_images, const float *in, const float *res,
+                float *out, float *splitk_ws) {
+    ConvKArgs a;
+    long tiles_total = 0;
+    bool fused_reduce = false;
+    int rc = conv_args(L, n_images, in, res, out, splitk_ws, a, &tiles_total, &fused_reduce);
+    if (rc) return rc;
     dim3 grid((unsigned)tiles_total, 1, L.splits);
     // With timing on, the kernel's own begin/end timestamps are attached to two events by the
     // launch itself (no extra markers on the stream, so nothing but the kernel is timed).
@@ -533,7 +579,6 @@ int launch_conv(const ConvLayer &L, hipStream_t stream, int n_images, const floa
         hipExtLaunchKernelGGL((KERNEL), grid, dim3(256), 0, stream, e0, e1, 0, a);           \
     else                                                                                     \
         hipLaunchKernelGGL((KERNEL), grid, dim3(256), 0, stream, a);
-    if (L.tile == 32 && L.cin % 64 != 0) return fail(GDPSO_ERR_ARG, "conv: the 32-row tile needs cin to be a multiple of 64");
     if (L.tile == 128) {
         GDPSO_LAUNCH((conv_gemm_kernel<128, 128, 32, 1>))
     } else if (L.tile == 64) {
@@ -544,15 +589,55 @@ int launch_conv(const ConvLayer &L, hipStream_t stream, int n_images, const floa
 #undef GDPSO_LAUNCH
     if (timed) {
         g_timing.used += 2;
-        g_timing.flops += L.flops_nominal * n_images;
-        for (int p = 0; p < L.nphase; ++p)
-            g_timing.executed += 2.0 * n_images * L.phase[p].hm * L.phase[p].wm * (double)L.phase[p].ntaps * L.cin * L.cout;
-        g_timing.bytes += 4.0 * ((double)n_images * L.hin * L.win * L.cin + (double)L.weight_floats + (double)a.slab * (res ? 2 : 1));
+        conv_account(L, n_images, a, res != nullptr);
     }
     if (L.splits > 1 && !fused_reduce) {
         const long quads = a.slab / 4;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ceil_div(quads, 256)), dim3(256), 0, stream, a.part, L.splits,
                            a.slab, L.cout, L.scale, L.shift, res, out, L.act);
+    }
+    GDPSO_HIP(hipGetLastError());
+    return GDPSO_OK;
+}
+
+// Two layers that read the same input, in one launch (see conv_gemm_pair_kernel).  Falls back
+// to two launches when the planner gave them different shapes or either is split.
+int launch_conv_pair(const ConvLayer &La, const ConvLayer &Lb, hipStream_t stream, int n_images, const float *in,
+                     float *out_a, float *out_b, float *splitk_ws) {
+    if (!g_pair_launch || La.tile != Lb.tile || La.splits != 1 || Lb.splits != 1) {
+        int rc = launch_conv(La, stream, n_images, in, nullptr, out_a, splitk_ws);
+        if (rc) return rc;
+        return launch_conv(Lb, stream, n_images, in, nullptr, out_b, splitk_ws);
+    }
+    ConvKArgs a, b;
+    long ta = 0, tb = 0;
+    bool fa = false, fb = false;
+    int rc;
+    if ((rc = conv_args(La, n_images, in, nullptr, out_a, splitk_ws, a, &ta, &fa))) return rc;
+    if ((rc = conv_args(Lb, n_images, in, nullptr, out_b, splitk_ws, b, &tb, &fb))) return rc;
+    const int ta_pad = (int)((ta + 7) / 8 * 8);
+    dim3 grid((unsigned)(ta_pad + tb), 1, 1);
+    const bool timed = g_timing.on && g_timing.used + 2 <= g_timing.events.size();
+    hipEvent_t e0 = timed ? g_timing.events[g_timing.used] : nullptr;
+    hipEvent_t e1 = timed ? g_timing.events[g_timing.used + 1] : nullptr;
+#define GDPSO_LAUNCH(KERNEL)                                                                          \
+    if (timed)                                                                                        \
+        hipExtLaunchKernelGGL((KERNEL), grid, dim3(256), 0, stream, e0, e1, 0, a, b, (int)ta, ta_pad); \
+    else                                                                                              \
+        hipLaunchKernelGGL((KERNEL), grid, dim3(256), 0, stream, a, b, (int)ta, ta_pad);
+    if (La.tile == 128) {
+        GDPSO_LAUNCH((conv_gemm_pair_kernel<128, 128, 32, 1>))
+    } else if (La.tile == 64) {
+        GDPSO_LAUNCH((conv_gemm_pair_kernel<64, 64, 32, 1>))
+    } else {
+        GDPSO_LAUNCH((conv_gemm_pair_kernel<32, 64, 64, 2>))
+    }
+#undef GDPSO_LAUNCH
+    if (timed) {
+        g_timing.used += 2;
+        conv_account(La, n_images, a, false);
+        conv_account(Lb, n_images, b, false);
+        g_timing.bytes -= 4.0 * n_images * La.hin * La.win * La.cin;  // the shared input is read once
     }
     GDPSO_HIP(hipGetLastError());
     return GDPSO_OK;

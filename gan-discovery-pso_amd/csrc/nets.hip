@@ -623,13 +623,14 @@ extern "C" int gdpso_assessor_forward(const gdpso_assessor *a, void *stream_, in
     int rc;
     if ((rc = conv_splitk_prepare(stream, sk))) return rc;
     for (const Bottleneck &b : L.blocks) {
-        if ((rc = launch_conv(b.c1, stream, n, x, nullptr, t1, sk))) return rc;
-        if ((rc = launch_conv(b.c2, stream, n, t1, nullptr, t2, sk))) return rc;
         const float *res = x;
-        if (b.has_ds) {
-            if ((rc = launch_conv(b.ds, stream, n, x, nullptr, sc, sk))) return rc;
+        if (b.has_ds) {  // identity_downsample and conv1 read the same input: one launch when their shapes allow
+            if ((rc = launch_conv_pair(b.ds, b.c1, stream, n, x, sc, t1, sk))) return rc;
             res = sc;
+        } else {
+            if ((rc = launch_conv(b.c1, stream, n, x, nullptr, t1, sk))) return rc;
         }
+        if ((rc = launch_conv(b.c2, stream, n, t1, nullptr, t2, sk))) return rc;
         if ((rc = launch_conv(b.c3, stream, n, t2, res, y, sk))) return rc;
         std::swap(x, y);
     }
