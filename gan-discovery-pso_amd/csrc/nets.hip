@@ -142,6 +142,110 @@ __global__ __launch_bounds__(512) void gen_last_kernel(const float *__restrict__
 }
 
 // ---------------------------------------------------------------------------------
+// The same layer on the matrix cores.  Per image, C[input pixel][kernel position (ky,kx)] =
+// A[pixel][channel] * W[channel][(ky,kx)] is a 196 x 16 x F product (v_mfma_f32_16x16x4_f32,
+// exact fp32); an output pixel is then the sum of the (at most) four entries of C whose input
+// pixel and kernel position land on it.  A lives in LDS with padded rows (conflict-free 16-byte
+// fragment reads); lane l of a wave holds A[row l&15][k] and W[k][col l&15] for the four
+// k = 16j + 4(l>>4) + s of step j, so one 16-byte read feeds four MFMAs.  Needs cin % 16 == 0.
+using f32x4_t = __attribute__((ext_vector_type(4))) float;
+constexpr int GL_MAX_KSTEPS = 8;  // cin <= 128
+
+__global__ __launch_bounds__(512) void gen_last_mfma_kernel(const float *__restrict__ a2, const float *__restrict__ w5,
+                                                            float bias, int hin, int cin, float *__restrict__ img,
+                                                            float *__restrict__ img01, const float *__restrict__ target,
+                                                            float *__restrict__ mse) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int side = 2 * hin, npix = side * side, nin = hin * hin;
+    const int nblk = (nin + 15) / 16, lda = cin + 4;
+    float *s_img = smem;                    // [npix]
+    float *s_red = s_img + npix;            // [3][8]
+    float *s_c = s_red + 32;                // [nblk * 16][16]
+    float *s_a2 = s_c + nblk * 16 * 16;     // [nblk * 16][lda]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = blockIdx.x;
+    const float *src = a2 + (size_t)n * nin * cin;
+    const int c4 = cin / 4;
+    for (int i = tid; i < nblk * 16 * c4; i += 512) {
+        const int r = i / c4, c = (i - r * c4) * 4;
+        f32x4_t v = 0.f;
+        if (r < nin) v = *(const f32x4_t *)&src[(size_t)r * cin + c];
+        *(f32x4_t *)&s_a2[r * lda + c] = v;
+    }
+    // W fragments: column l&15 is the kernel position ky*4+kx, stored as w5[position][channel]
+    const int lrow = lane & 15, lk = lane >> 4, ksteps = cin / 16;
+    f32x4_t bfrag[GL_MAX_KSTEPS];
+#pragma unroll
+    for (int j = 0; j < GL_MAX_KSTEPS; ++j)
+        bfrag[j] = j < ksteps ? *(const f32x4_t *)&w5[(size_t)lrow * cin + 16 * j + 4 * lk] : (f32x4_t)0.f;
+    __syncthreads();
+    for (int b = wave; b < nblk; b += 8) {
+        f32x4_t acc = 0.f;
+        const float *pa = s_a2 + (b * 16 + lrow) * lda + 4 * lk;
+#pragma unroll
+        for (int j = 0; j < GL_MAX_KSTEPS; ++j) {
+            if (j < ksteps) {
+                const f32x4_t av = *(const f32x4_t *)(pa + 16 * j);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bfrag[j][s], acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_c[(b * 16 + 4 * lk + r) * 16 + lrow] = acc[r];
+    }
+    __syncthreads();
+    // gather the four contributions of every output pixel, bias + tanh, per-image min / max
+    float mn = INFINITY, mx = -INFINITY, se = 0.f;
+    float *dst = img ? img + (size_t)n * npix : nullptr;
+    const float *tg = target ? target + (size_t)n * npix : nullptr;
+    for (int i = tid; i < npix; i += 512) {
+        const int oy = i / side, ox = i - oy * side;
+        const int py = oy & 1, my = oy >> 1, px = ox & 1, mxx = ox >> 1;
+        // (input offset, kernel index) = (0, 1), (-1, 3) for even rows; (0, 2), (+1, 0) for odd; same along x
+        const int iy1 = my + (py ? 1 : -1), ky0 = py ? 2 : 1, ky1 = py ? 0 : 3;
+        const int ix1 = mxx + (px ? 1 : -1), kx0 = px ? 2 : 1, kx1 = px ? 0 : 3;
+        const bool yok = (unsigned)iy1 < (unsigned)hin, xok = (unsigned)ix1 < (unsigned)hin;
+        const float t00 = s_c[(my * hin + mxx) * 16 + ky0 * 4 + kx0];
+        const float t01 = xok ? s_c[(my * hin + ix1) * 16 + ky0 * 4 + kx1] : 0.f;
+        const float t10 = yok ? s_c[(iy1 * hin + mxx) * 16 + ky1 * 4 + kx0] : 0.f;
+        const float t11 = (yok && xok) ? s_c[(iy1 * hin + ix1) * 16 + ky1 * 4 + kx1] : 0.f;
+        const float v = tanhf(((t00 + t01) + (t10 + t11)) + bias);
+        s_img[i] = v;
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+        if (dst) dst[i] = v;
+        if (tg) {
+            const float dlt = tg[i] - v;
+            se = fmaf(dlt, dlt, se);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, o));
+        mx = fmaxf(mx, __shfl_xor(mx, o));
+        se += __shfl_xor(se, o);
+    }
+    if (lane == 0) {
+        s_red[wave] = mn;
+        s_red[8 + wave] = mx;
+        s_red[16 + wave] = se;
+    }
+    __syncthreads();
+    mn = s_red[0];
+    mx = s_red[8];
+    se = s_red[16];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        mn = fminf(mn, s_red[k]);
+        mx = fmaxf(mx, s_red[8 + k]);
+        se += s_red[16 + k];
+    }
+    const float range = mx - mn;
+    float *d01 = img01 + (size_t)n * npix;
+    for (int i = tid; i < npix; i += 512) d01[i] = (s_img[i] - mn) / range;  // each thread rescales the pixels it wrote
+    if (mse && tid == 0) mse[n] = se / (float)npix;
+}
+
+// ---------------------------------------------------------------------------------
 // Assessor stem, fused: Conv2d(1 -> 64, k7, s2, p3, no bias) + BatchNorm + ReLU +
 // MaxPool2d(3, s2, p1) (reference src/pso/util_cnn.py:85-88, 103-106).  NHWC output.
 // Grid (image, band of pooled rows).  Lane = output channel (its 49 weights live in
@@ -343,6 +447,8 @@ struct gdpso_generator {
     const float *w5;
     float b5;
     int num_cus;
+    bool last_mfma;            // the last layer runs on the matrix cores (features % 16 == 0, <= 128)
+    size_t last_mfma_lds_max;  // dynamic LDS the MFMA kernel may use on this device
     DeviceArena arena;
 };
 
@@ -415,6 +521,14 @@ extern "C" int gdpso_generator_create(gdpso_generator **out, int z_dim, int feat
         if ((rc = g->arena.upload(w5, &g->w5))) { delete g; return rc; }
         g->b5 = t[13][0];
     }
+    {
+        const char *e = getenv("GDPSO_GEN_LAST_MFMA");
+        g->last_mfma = (e ? e[0] != '0' : true) && features_g % 16 == 0 && features_g <= 16 * GL_MAX_KSTEPS;
+        g->last_mfma_lds_max = 64 * 1024;
+        if (g->last_mfma &&
+            hipFuncSetAttribute((const void *)gen_last_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) == hipSuccess)
+            g->last_mfma_lds_max = 152 * 1024;
+    }
     *out = g;
     return GDPSO_OK;
 }
@@ -450,7 +564,11 @@ extern "C" int gdpso_generator_forward(const gdpso_generator *g, void *stream_, 
     const int hin = 2 * g->k1;
     const size_t base = ((size_t)g->side * g->side + 32) * sizeof(float);
     const size_t staged = base + (size_t)hin * hin * g->features * sizeof(float);
-    if (staged <= 64 * 1024)
+    const int nblk = (hin * hin + 15) / 16;
+    const size_t mfma_lds = base + ((size_t)nblk * 16 * 16 + (size_t)nblk * 16 * (g->features + 4)) * sizeof(float);
+    if (g->last_mfma && mfma_lds <= g->last_mfma_lds_max)
+        hipLaunchKernelGGL(gen_last_mfma_kernel, dim3(n), dim3(512), mfma_lds, stream, a2, g->w5, g->b5, hin, g->features, img, img01, target, mse);
+    else if (staged <= 64 * 1024)
         hipLaunchKernelGGL(gen_last_kernel<true>, dim3(n), dim3(512), staged, stream, a2, g->w5, g->b5, hin, g->features, img, img01, target, mse);
     else
         hipLaunchKernelGGL(gen_last_kernel<false>, dim3(n), dim3(512), base, stream, a2, g->w5, g->b5, hin, g->features, img, img01, target, mse);
