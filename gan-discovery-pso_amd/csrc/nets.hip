@@ -319,6 +319,98 @@ __global__ __launch_bounds__(512) void stem_kernel(const float *__restrict__ img
 }
 
 // ---------------------------------------------------------------------------------
+// The stem on the matrix cores, one workgroup per image (used when the whole convolution
+// output of an image fits LDS, i.e. the 28x28 inputs of the reference).  Per image the 7x7/2
+// convolution is a (ho*ho) x 64 x 49 product: A[pixel][k = ky*7+kx] is gathered from the
+// zero-padded image in LDS, B[k][channel] are the weights (K padded to 52 with zero weights),
+// v_mfma_f32_16x16x4_f32 with lane l holding A[row l&15][k = 4t + (l>>4)] and B[that k][col l&15]
+// at step t.  A wave takes 16-pixel row blocks round-robin and all four 16-channel column blocks
+// of each (its 52 weight values stay in registers).  BatchNorm + ReLU are applied on the way to
+// LDS, then the 3x3/2 max pool reads the conv image from LDS.
+constexpr int STEM_KSTEPS = 13;  // ceil(49 / 4)
+
+__global__ __launch_bounds__(512) void stem_mfma_kernel(const float *__restrict__ img01, const float *__restrict__ w,
+                                                        const float *__restrict__ scale, const float *__restrict__ shift,
+                                                        int side, int ho, int hp, int ps, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int prows = side + 6, npx = ho * ho, nblk = (npx + 15) / 16;
+    constexpr int LDC = 64 + 4;
+    float *s_img = smem;                 // [prows][ps], zero border of 3
+    float *s_conv = smem + prows * ps;   // [nblk * 16][LDC]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = blockIdx.x;
+    const float *src = img01 + (size_t)n * side * side;
+    for (int i = tid; i < prows * ps; i += 512) {
+        const int y = i / ps - 3, x = i % ps - 3;
+        s_img[i] = ((unsigned)y < (unsigned)side && (unsigned)x < (unsigned)side) ? src[y * side + x] : 0.f;
+    }
+    // weights [49][64] -> LDS rows of 80 floats (the conv buffer is free until the products start),
+    // read with 16-byte loads; the fragment reads below are then conflict-free
+    constexpr int LDW = 80;
+    for (int i = tid; i < 49 * 16; i += 512) {
+        const int k = i >> 4, c = (i & 15) * 4;
+        *(f32x4_t *)&s_conv[k * LDW + c] = *(const f32x4_t *)&w[k * 64 + c];
+    }
+    const int lrow = lane & 15, lk = lane >> 4;
+    float sc[4], sh[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        sc[cb] = scale[cb * 16 + lrow];
+        sh[cb] = shift[cb * 16 + lrow];
+    }
+    __syncthreads();
+    // this lane's k per step, as an offset into the padded image, and its weights
+    int koff[STEM_KSTEPS];
+    float bw[STEM_KSTEPS][4];
+#pragma unroll
+    for (int t = 0; t < STEM_KSTEPS; ++t) {
+        const int k = 4 * t + lk;
+        const int kk = k < 49 ? k : 0;
+        koff[t] = (kk / 7) * ps + kk % 7;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) bw[t][cb] = k < 49 ? s_conv[k * LDW + cb * 16 + lrow] : 0.f;
+    }
+    __syncthreads();
+    for (int b = wave; b < nblk; b += 8) {
+        const int px = min(b * 16 + lrow, npx - 1);  // rows past the image repeat the last pixel; they are never read back
+        const int y = px / ho, x = px - y * ho;
+        const float *base = s_img + (2 * y) * ps + 2 * x;  // padded coordinates: +3 - 3
+        float av[STEM_KSTEPS];
+#pragma unroll
+        for (int t = 0; t < STEM_KSTEPS; ++t) av[t] = base[koff[t]];
+        f32x4_t acc[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) acc[cb] = 0.f;
+#pragma unroll
+        for (int t = 0; t < STEM_KSTEPS; ++t)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bw[t][cb], acc[cb], 0, 0, 0);
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                s_conv[(b * 16 + 4 * lk + r) * LDC + cb * 16 + lrow] = fmaxf(acc[cb][r] * sc[cb] + sh[cb], 0.f);
+    }
+    __syncthreads();
+    // MaxPool2d(3, s2, p1); consecutive threads take consecutive channels
+    for (int e = tid; e < hp * hp * 64; e += 512) {
+        const int c = e & 63, pp = e >> 6, pr = pp / hp, pc = pp - pr * hp;
+        float m = -INFINITY;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int cy = 2 * pr + dy;
+            if ((unsigned)cy >= (unsigned)ho) continue;
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int cx = 2 * pc + dx;
+                if ((unsigned)cx >= (unsigned)ho) continue;
+                m = fmaxf(m, s_conv[(cy * ho + cx) * LDC + c]);
+            }
+        }
+        out[((size_t)n * hp * hp + pp) * 64 + c] = m;
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // Assessor head, fused: AdaptiveMaxPool2d(1) over the last feature map, Linear(C -> n_class)
 // (reference src/pso/util_cnn.py:113-115), softmax + class pick + clamp + mode + eps
 // (src/pso/util_discovery.py:69-80) and the inverter variant's weighted sum (:86-101).
@@ -731,7 +823,16 @@ extern "C" int gdpso_assessor_forward(const gdpso_assessor *a, void *stream_, in
     char *ws = (char *)workspace;
     float *x = (float *)(ws + L.x), *y = (float *)(ws + L.y), *t1 = (float *)(ws + L.t1), *t2 = (float *)(ws + L.t2);
     float *sc = (float *)(ws + L.sc), *sk = (float *)(ws + L.splitk);
-    {
+    static const bool stem_mfma = [] {
+        const char *e = getenv("GDPSO_STEM_MFMA");
+        return e ? e[0] != '0' : true;
+    }();
+    const int mps = (a->side + 6 + 3) / 4 * 4;
+    const size_t mfma_smem = ((size_t)(a->side + 6) * mps + (size_t)((a->ho * a->ho + 15) / 16 * 16) * 68) * sizeof(float);
+    if (stem_mfma && mfma_smem <= 64 * 1024) {
+        hipLaunchKernelGGL(stem_mfma_kernel, dim3(n), dim3(512), mfma_smem, stream, img01, a->stem_w, a->stem_scale, a->stem_shift,
+                           a->side, a->ho, a->hp, mps, x);
+    } else {
         const int rows = 2 * a->stem_band + 1;
         const size_t smem = ((size_t)(a->side + 6) * a->stem_ps + (size_t)rows * a->ho * 64) * sizeof(float);
         dim3 grid(n, ceil_div(a->hp, a->stem_band));
