@@ -183,10 +183,10 @@ def main():
             with open(os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")) as f:
                 pm = json.load(f)
             if p == 512 and z_dim == 10:
-                traffic = pm["kernels"]["gdpso::conv_gemm_kernel<64, 64>"]["hbm_bytes_per_launch"]
+                traffic = pm["kernels"]["conv_gemm (all instantiations)"]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
-        roofline = {"bound": "mfma", "kernel": "conv_gemm_kernel (fp32-input MFMA implicit GEMM)",
+        roofline = {"bound": "mfma", "kernel": "conv_gemm_kernel / conv_gemm_pair_kernel, all instantiations (fp32-input MFMA implicit GEMM)",
                     "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_hbm_traffic.json)",

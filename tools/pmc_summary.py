@@ -28,6 +28,14 @@ def main():
     out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (one pass each) -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline",
            "corrections": "counter values are KiB; FETCH_SIZE doubled (gfx950 tallies 128-B requests of 16-B-per-lane reads at 64 B); WRITE_SIZE as read",
            "kernels": {}}
+    # every instantiation of the convolution kernel (tile shapes, paired launches) as one entry
+    for a in (fe, wr):
+        tot = [0, 0.0]
+        for k in list(a):
+            if "conv_gemm" in k:
+                tot[0] += a[k][0]
+                tot[1] += a[k][1]
+        a["conv_gemm (all instantiations)"] = tot
     for k in fe:
         if fe[k][1] < 1000:
             continue
