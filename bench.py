@@ -123,7 +123,7 @@ def main():
         if comm is None:
             sw.iterate(first, count, spec, 1.496, 1.496, False, False, 1e-5, True, seed=42)
         else:
-            deep = bool(os.environ.get("GDPSO_BENCH_DEBUG"))
+            deep = os.environ.get("GDPSO_BENCH_DEBUG") == "1"  # any other value: progress lines and the hang dump only
             for i in range(first, first + count):
                 sw.evaluate(i, spec)
                 if deep: torch.cuda.synchronize(dev); dbg(f"{i} evaluate ok")

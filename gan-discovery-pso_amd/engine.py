@@ -497,28 +497,30 @@ class TorchComm:
         import torch.distributed as dist
         self.dist, self.group = dist, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-        # gloo handles device tensors through host staging outside stream order (rehearsal
-        # path only): drain the device first.  RCCL collectives are stream-ordered.
-        self.drain_first = dist.get_backend(group) == "gloo"
+        # gloo has no stream-ordered collectives on device tensors: with it (CPU tests, rehearsal of
+        # several ranks on one GPU) device tensors are staged through the host explicitly.  RCCL
+        # collectives run in stream order on the device tensors themselves.
+        self.host_staged = dist.get_backend(group) == "gloo"
 
-    def _drain(self, t):
-        if self.drain_first and t.is_cuda:
-            torch.cuda.synchronize(t.device)
+    def _all_gather_flat(self, out_flat: torch.Tensor, inp_flat: torch.Tensor):
+        if self.host_staged and out_flat.is_cuda:
+            host_in = inp_flat.detach().cpu()  # waits for the producing kernels
+            host_out = torch.empty(out_flat.numel(), dtype=out_flat.dtype)
+            self.dist.all_gather_into_tensor(host_out, host_in, group=self.group)
+            out_flat.copy_(host_out)
+        else:
+            self.dist.all_gather_into_tensor(out_flat, inp_flat, group=self.group)
 
     def all_gather(self, out: torch.Tensor, inp: torch.Tensor):
         # out [W, d+2] is the swarm's candidate table; inp is this rank's row of it
-        self._drain(out)
-        self.dist.all_gather_into_tensor(out.view(-1), inp.clone().view(-1), group=self.group)
-        self._drain(out)
+        self._all_gather_flat(out.view(-1), inp.clone().view(-1))
 
     def gather_positions(self, pos: torch.Tensor, n_global: int) -> torch.Tensor:
         n_max = -(-n_global // self.world)
         pad = torch.zeros(n_max, pos.shape[1], dtype=pos.dtype, device=pos.device)
         pad[:pos.shape[0]] = pos
         allp = torch.empty(self.world * n_max, pos.shape[1], dtype=pos.dtype, device=pos.device)
-        self._drain(pad)
-        self.dist.all_gather_into_tensor(allp.view(-1), pad.view(-1), group=self.group)
-        self._drain(pad)
+        self._all_gather_flat(allp.view(-1), pad.view(-1))
         if n_global == self.world * n_max:
             return allp
         rows = []
