@@ -82,6 +82,9 @@ int launch_conv(const ConvLayer &L, hipStream_t stream, int n_images, const floa
 int launch_conv_pair(const ConvLayer &La, const ConvLayer &Lb, hipStream_t stream, int n_images, const float *in,
                      float *out_a, float *out_b, float *splitk_ws);
 
+int launch_conv_then_1x1(const ConvLayer &La, const ConvLayer &Lb, hipStream_t stream, int n_images, const float *in,
+                         float *mid, const float *res, float *out, float *splitk_ws);
+
 // host-side helpers (pack.cpp)
 struct DeviceArena {
     std::vector<void *> blocks;

@@ -61,6 +61,17 @@ struct ConvKArgs {
     int tile_end[MAX_PHASES];  // running count of M-tiles up to and including each phase (INT_MAX past the last)
 };
 
+// A 1x1 convolution over the same pixels, applied to this layer's output tile before it leaves
+// the workgroup (this layer has exactly 64 output channels = the whole K of the next one).
+struct FuseArgs {
+    const float *wt;     // [cout][64]
+    const float *scale;
+    const float *shift;
+    const float *res;    // residual added before the activation, or null
+    float *out;
+    int cout, act;
+};
+
 // What a workgroup needs to know about its phase (all wave-uniform).
 struct PhaseInfo {
     int M, hm, wm;      // rows of this phase = n_images * hm * wm
@@ -181,8 +192,9 @@ __device__ __forceinline__ void conv_store_tile(const ConvKArgs &a, float *lds, 
 // tile.  KW = 2 (BM = 32): two waves side by side cover the tile and the other two take the
 // second half of every K-tile; the two halves are added through LDS before the epilogue.  That
 // shape doubles the number of workgroups of a small-M layer without split-K slabs.
-template <int BM, int BN, int BKT, int KW>
-__device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, const int nt, float *lds) {
+template <int BM, int BN, int BKT, int KW, bool FUSE = false>
+__device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, const int nt, float *lds, const FuseArgs *fuse = nullptr) {
+    static_assert(!FUSE || (BM == 64 && BN == 64 && KW == 1), "the fused tail is written for the 64x64 tile");
     static_assert(BKT / KW == 32, "every wave consumes 32 k per K-tile");
     static_assert(KW == 1 || BM == 32, "the K-split layout is for 32-row tiles");
     constexpr int LDA = BKT + 4;  // 144- or 272-byte rows: ds_read_b128 of consecutive rows is conflict-free
@@ -356,6 +368,80 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, cons
 #undef GDPSO_SSTORE
 #undef GDPSO_LOADFRAG
 
+    if constexpr (FUSE) {
+        // This layer's 64 x 64 tile, activated, becomes the A operand (K = 64) of the next layer;
+        // its weights come through LDS one 64-channel column block at a time, prefetched a
+        // block ahead; every block ends in the usual LDS-staged epilogue with its residual.
+        const FuseArgs &f = *fuse;
+        constexpr int LD2 = 64 + 4;
+        float *sA2 = lds, *sB2 = lds + 64 * LD2, *sC2 = lds + 2 * 64 * LD2;
+        {
+            const int col = wc * 32 + l31;
+            const float sc1 = a.scale[n0 + col], sh1 = a.shift[n0 + col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                sA2[(wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LD2 + col] = apply_act(acc[0][0][r] * sc1 + sh1, a.act);
+        }
+        const int c4 = tid & 15, r0 = tid >> 4;  // 16 threads x 16 B per 64-float row, 16 rows per pass
+        const int hw2 = P.hm * P.wm;
+        const bool remap = a.out_mul != 1 || P.hm != a.hout || P.wm != a.wout;
+        long off[4];
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int m = m0 + pass * 16 + r0;
+            size_t pix = (size_t)m;
+            if (remap && m < P.M) {
+                const int n = m / hw2, rr = m - n * hw2;
+                const int my = rr / P.wm, mx = rr - my * P.wm;
+                pix = ((size_t)n * a.hout + my * a.out_mul + P.off_y) * a.wout + mx * a.out_mul + P.off_x;
+            }
+            off[pass] = m < P.M ? (long)(pix * f.cout + c4 * 4) : -1;
+        }
+        const int nblocks = f.cout / 64;
+        f32x4 rw[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) rw[p] = *(global_f32x4_ptr)(f.wt + (size_t)(r0 + 16 * p) * 64 + c4 * 4);
+        for (int cb = 0; cb < nblocks; ++cb) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) *(f32x4 *)&sB2[(r0 + 16 * p) * LD2 + c4 * 4] = rw[p];
+            if (cb + 1 < nblocks) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) rw[p] = *(global_f32x4_ptr)(f.wt + (size_t)((cb + 1) * 64 + r0 + 16 * p) * 64 + c4 * 4);
+            }
+            f32x4 rres[4];
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                rres[pass] = 0.f;
+                if (f.res && off[pass] >= 0) rres[pass] = *(global_f32x4_ptr)(f.res + off[pass] + cb * 64);
+            }
+            __syncthreads();
+            f32x16 acc2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+            const float *pa2 = sA2 + (wr * 32 + l31) * LD2 + half * 4;
+            const float *pb2 = sB2 + (wc * 32 + l31) * LD2 + half * 4;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const f32x4 av2 = *(const f32x4 *)(pa2 + g * 8), bv2 = *(const f32x4 *)(pb2 + g * 8);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av2[s], bv2[s], acc2, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sC2[(wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LD2 + wc * 32 + l31] = acc2[r];
+            __syncthreads();
+            const f32x4 sc2 = *(const f32x4 *)(f.scale + cb * 64 + c4 * 4), sh2 = *(const f32x4 *)(f.shift + cb * 64 + c4 * 4);
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                if (off[pass] < 0) continue;
+                f32x4 v = *(const f32x4 *)&sC2[(pass * 16 + r0) * LD2 + c4 * 4];
+                v = v * sc2 + sh2 + rres[pass];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = apply_act(v[q], f.act);
+                *(f32x4 *)(f.out + off[pass] + cb * 64) = v;
+            }
+        }
+        return;
+    }
     // Epilogue through LDS.  Accumulator register r of lane l is
     // C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]; the tile is first laid out row-major
     // in LDS (the K loop's last barrier has retired every operand read).
@@ -390,6 +476,13 @@ template <int BM, int BN, int BKT, int KW>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * (BKT + 4)];
     conv_tile<BM, BN, BKT, KW>(a, blockIdx.x, gridDim.x, lds);
+}
+
+// A convolution with 64 output channels followed by a 1x1 convolution, one launch: conv2 + conv3
+// of the first-stage bottleneck blocks.  The intermediate never leaves the workgroup.
+__global__ __launch_bounds__(256, 2) void conv_gemm_fused_kernel(const ConvKArgs a, const FuseArgs f) {
+    __shared__ __attribute__((aligned(16))) float lds[3 * 64 * 68];
+    conv_tile<64, 64, 32, 1, true>(a, blockIdx.x, gridDim.x, lds, &f);
 }
 
 // Two independent layers in one grid (same tile shape, no split-K): the first tiles_a_pad
@@ -452,6 +545,11 @@ struct ConvTiming {
 // (last-arriver) reduction, which only pays on much longer K loops / larger grids.
 static bool g_allow_tile32 = [] {
     const char *e = getenv("GDPSO_CONV_TILE32");
+    return e ? e[0] != '0' : true;
+}();
+
+static bool g_fuse_1x1 = [] {
+    const char *e = getenv("GDPSO_CONV_FUSE_1X1");
     return e ? e[0] != '0' : true;
 }();
 
@@ -595,6 +693,44 @@ int launch_conv(const ConvLayer &L, hipStream_t stream, int n_images, const floa
         const long quads = a.slab / 4;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ceil_div(quads, 256)), dim3(256), 0, stream, a.part, L.splits,
                            a.slab, L.cout, L.scale, L.shift, res, out, L.act);
+    }
+    GDPSO_HIP(hipGetLastError());
+    return GDPSO_OK;
+}
+
+// La (64 output channels, 64x64 tiles, unsplit) followed by the 1x1 convolution Lb over the same
+// pixels, in one launch when the shapes allow; `mid` receives La's output only on the fallback path.
+int launch_conv_then_1x1(const ConvLayer &La, const ConvLayer &Lb, hipStream_t stream, int n_images, const float *in,
+                         float *mid, const float *res, float *out, float *splitk_ws) {
+    const bool ok = g_fuse_1x1 && La.tile == 64 && La.splits == 1 && La.cout == 64 && Lb.cin == 64 && Lb.nphase == 1 &&
+                    Lb.phase[0].ntaps == 1 && Lb.in_stride == 1 && Lb.out_mul == 1 && Lb.hout == La.hout && Lb.wout == La.wout &&
+                    Lb.cout % 64 == 0 && Lb.phase[0].wstride == 64;
+    if (!ok) {
+        int rc = launch_conv(La, stream, n_images, in, nullptr, mid, splitk_ws);
+        if (rc) return rc;
+        return launch_conv(Lb, stream, n_images, mid, res, out, splitk_ws);
+    }
+    ConvKArgs a;
+    long tiles = 0;
+    bool fr = false;
+    int rc = conv_args(La, n_images, in, nullptr, nullptr, splitk_ws, a, &tiles, &fr);
+    if (rc) return rc;
+    FuseArgs f;
+    f.wt = Lb.wt; f.scale = Lb.scale; f.shift = Lb.shift; f.res = res; f.out = out; f.cout = Lb.cout; f.act = Lb.act;
+    if ((long)n_images * Lb.hout * Lb.wout * Lb.cout * 4 >= (1L << 31)) return fail(GDPSO_ERR_ARG, "conv: output larger than 2 GiB");
+    dim3 grid((unsigned)tiles, 1, 1);
+    const bool timed = g_timing.on && g_timing.used + 2 <= g_timing.events.size();
+    if (timed) {
+        hipExtLaunchKernelGGL(conv_gemm_fused_kernel, grid, dim3(256), 0, stream, g_timing.events[g_timing.used],
+                              g_timing.events[g_timing.used + 1], 0, a, f);
+        g_timing.used += 2;
+        conv_account(La, n_images, a, false);
+        ConvKArgs b;
+        b.slab = (long)n_images * Lb.hout * Lb.wout * Lb.cout;
+        conv_account(Lb, n_images, b, res != nullptr);
+        g_timing.bytes -= 2 * 4.0 * n_images * Lb.hin * Lb.win * Lb.cin;  // the intermediate is neither written nor read
+    } else {
+        hipLaunchKernelGGL(conv_gemm_fused_kernel, grid, dim3(256), 0, stream, a, f);
     }
     GDPSO_HIP(hipGetLastError());
     return GDPSO_OK;

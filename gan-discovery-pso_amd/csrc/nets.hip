@@ -849,8 +849,7 @@ extern "C" int gdpso_assessor_forward(const gdpso_assessor *a, void *stream_, in
         } else {
             if ((rc = launch_conv(b.c1, stream, n, x, nullptr, t1, sk))) return rc;
         }
-        if ((rc = launch_conv(b.c2, stream, n, t1, nullptr, t2, sk))) return rc;
-        if ((rc = launch_conv(b.c3, stream, n, t2, res, y, sk))) return rc;
+        if ((rc = launch_conv_then_1x1(b.c2, b.c3, stream, n, t1, t2, res, y, sk))) return rc;
         std::swap(x, y);
     }
     hipLaunchKernelGGL(head_kernel, dim3(n), dim3(256), 0, stream, x, a->feat_hw, a->feat_c, a->fc_w, a->fc_b, a->n_class, logits,
