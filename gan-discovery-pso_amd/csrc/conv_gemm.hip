@@ -13,16 +13,22 @@
 // through ~50 layers.  The instruction is 16x slower than bf16 MFMA, so the kernel is
 // MFMA-issue bound: one ds_read_b128 per operand feeds four MFMAs (256 cycles).
 //
-// Tile: BM x BN outputs per 256-thread workgroup (4 waves as 2x2, each (BM/2)x(BN/2)),
-// BK = 32, two LDS buffers, register prefetch of the next K-tile, one barrier per K-tile.
-// Small-M layers (late ResNet stages at 1x1..4x4) use 64x64 tiles plus split-K over
-// blockIdx.z with fp32 partial slabs and a fused reduce+epilogue kernel.
+// Tile: BM x BN outputs per 256-thread workgroup, two LDS buffers, register prefetch of the
+// next K-tile, one barrier per K-tile, LDS-staged 16-byte epilogue.  Three shapes: 128x128 and
+// 64x64 (four waves as 2x2, K-tiles of 32) and 32x64 (two waves side by side, the other two
+// take the second half of every 64-wide K-tile; halves added through LDS), which doubles the
+// workgroups of the small-M layers of the late ResNet stages.  Layers that still have fewer
+// workgroups than CUs split K over blockIdx.z into fp32 slabs summed by splitk_reduce_kernel.
 //
 // A layer is a list of phases, each an output sub-grid with its own tap list.  Padded
 // convolutions are split into border classes (first / middle / last output rows x columns):
 // inside a class every tap is in range for every row, so the taps that would only multiply
 // padding zeros are not in its list at all.  On the small maps of the late ResNet stages
 // that is most of the nominal work (a 3x3 convolution on a 2x2 map has 4 live taps of 9).
+//
+// Two launch-saving forms share the tile code: two layers that read the same input in one
+// grid (identity_downsample + conv1), and a 64-channel layer whose activated tile stays in LDS
+// as the A operand of the 1x1 layer behind it (conv2 + conv3 of the first stage).
 #include <hip/hip_ext.h>
 
 #include <cstdlib>
@@ -815,6 +821,45 @@ extern "C" int gdpso_conv_timing_end(double *total_ms, int *launches, double *fl
 
 extern "C" double gdpso_conv_timing_bytes(void) { return gdpso::g_timing.bytes; }
 extern "C" double gdpso_conv_timing_executed_flops(void) { return gdpso::g_timing.executed; }
+
+extern "C" int gdpso_conv_plan_describe(int n_images, int hin, int cin, int cout, int ksize, int stride, int pad,
+                                        int transposed, int num_cus, int *out, int max_ints) {
+    using namespace gdpso;
+    if (!(n_images > 0 && hin > 0 && cin > 0 && cout > 0 && num_cus > 0 && out && max_ints > 0)) {
+        set_error("conv_plan_describe: bad argument");
+        return -GDPSO_ERR_ARG;
+    }
+    if (!transposed && !(ksize > 0 && stride > 0 && pad >= 0 && hin + 2 * pad >= ksize)) {
+        set_error("conv_plan_describe: bad window");
+        return -GDPSO_ERR_ARG;
+    }
+    ConvLayer L;
+    std::vector<float> packed;
+    if (transposed) {
+        std::vector<float> w((size_t)cin * cout * 16, 0.f);
+        make_convt_k4s2p1(L, w.data(), cin, cout, hin, hin, ACT_NONE, packed);
+    } else {
+        std::vector<float> w((size_t)cout * cin * ksize * ksize, 0.f);
+        make_conv(L, w.data(), cout, cin, ksize, ksize, stride, pad, hin, hin, ACT_NONE, packed);
+    }
+    if (plan_conv(L, n_images, num_cus)) return -GDPSO_ERR_ARG;
+    std::vector<int> v = {L.nphase, L.tile, L.splits, L.hout, L.wout};
+    for (int p = 0; p < L.nphase; ++p) {
+        const ConvPhase &P = L.phase[p];
+        for (int x : {P.ntaps, P.off_y, P.off_x, P.hm, P.wm, P.in_y0, P.in_x0}) v.push_back(x);
+        for (int t = 0; t < P.ntaps; ++t) {
+            v.push_back(P.dy[t]);
+            v.push_back(P.dx[t]);
+            v.push_back(P.wtap[t]);
+        }
+    }
+    if ((int)v.size() > max_ints) {
+        set_error("conv_plan_describe: output buffer too small");
+        return -GDPSO_ERR_ARG;
+    }
+    std::copy(v.begin(), v.end(), out);
+    return (int)v.size();
+}
 
 // Times one convolution layer in isolation (development / tuning aid): random weights and
 // inputs, `reps` back-to-back launches bracketed by HIP events.  tile = 0 / splits = 0 keep

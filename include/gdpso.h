@@ -262,9 +262,20 @@ double gdpso_conv_timing_bytes(void);
  * fall in the padding (they are not multiplied at all). */
 double gdpso_conv_timing_executed_flops(void);
 
+/* No counterpart in the reference: the launch plan of one ksize x ksize convolution layer, computed
+ * on the host alone (no device needed; for tests and tuning).  transposed != 0 describes
+ * ConvTranspose2d(k4, s2, p1) instead (ksize, stride, pad ignored).  Writes to `out` (at most
+ * max_ints ints): nphase, tile, splits, hout, wout, then for every phase
+ *   ntaps, off_y, off_x, hm, wm, in_y0, in_x0, followed by ntaps triples (dy, dx, weight slot).
+ * Phase p covers the output pixels (my*out_mul + off_y, mx*out_mul + off_x), (my, mx) in hm x wm,
+ * and reads input pixel (my*in_stride + in_y0 + dy, mx*in_stride + in_x0 + dx) for each tap.
+ * Returns the number of ints written, or a negative error code. */
+int gdpso_conv_plan_describe(int n_images, int hin, int cin, int cout, int ksize, int stride, int pad, int transposed,
+                             int num_cus, int *out, int max_ints);
+
 /* No counterpart in the reference: times one ksize x ksize convolution layer in isolation
  * on random data (allocates and frees its own buffers; a development / tuning aid).
- * tile (0, 64 or 128) and splits (0 = planner's choice) override the launch plan. */
+ * tile (0 = planner's choice, 32, 64 or 128) and splits (0 = planner's choice) override the launch plan. */
 int gdpso_conv_probe(int n_images, int hin, int cin, int cout, int ksize, int stride, int pad, int tile,
                      int splits, int with_res, int reps, double *avg_us, int *tile_used, int *splits_used);
 

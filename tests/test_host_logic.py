@@ -80,3 +80,100 @@ def test_no_cpu_fallback(synth):
                                                torch.device("cpu"), iid_classes=list(range(8)))
     with pytest.raises(lib.GdpsoError, match="no CPU fallback"):
         disc.fitness(10, np.zeros(10))
+
+
+# ----------------------------------------------------------------- convolution launch plans
+def _describe(lib, n, hin, cin, cout, k, stride, pad, transposed=0, cus=256):
+    import ctypes as C
+    buf = (C.c_int * 8192)()
+    got = lib.lib().gdpso_conv_plan_describe(n, hin, cin, cout, k, stride, pad, transposed, cus, buf, 8192)
+    assert got > 0, lib.lib().gdpso_last_error()
+    v = list(buf[:got])
+    nphase, tile, splits, hout, wout = v[:5]
+    pos, phases = 5, []
+    for _ in range(nphase):
+        ntaps, off_y, off_x, hm, wm, in_y0, in_x0 = v[pos:pos + 7]
+        pos += 7
+        taps = [tuple(v[pos + 3 * t:pos + 3 * t + 3]) for t in range(ntaps)]
+        pos += 3 * ntaps
+        phases.append(dict(off=(off_y, off_x), grid=(hm, wm), origin=(in_y0, in_x0), taps=taps))
+    assert pos == got
+    return dict(tile=tile, splits=splits, hout=hout, wout=wout, phases=phases)
+
+
+@pytest.mark.parametrize("hin,k,stride,pad", [(7, 3, 1, 1), (7, 3, 2, 1), (4, 3, 1, 1), (4, 3, 2, 1), (2, 3, 1, 1), (2, 3, 2, 1),
+                                             (1, 3, 1, 1), (16, 3, 1, 1), (28, 4, 2, 1), (14, 4, 2, 1), (7, 7, 2, 0), (7, 1, 1, 0),
+                                             (7, 1, 2, 0), (9, 7, 1, 3), (5, 5, 1, 2)])
+def test_conv_phases_cover_exactly_the_in_range_taps(pkg, hin, k, stride, pad):
+    """Border-class phases of a padded convolution (host-side planning, no device): every output
+    pixel belongs to exactly one phase, and the (input pixel, kernel tap) pairs that phase gives
+    it are exactly the taps that fall inside the input -- nothing from the padding, nothing lost."""
+    lib = importlib.import_module("gan-discovery-pso_amd._lib")
+    d = _describe(lib, 8, hin, 64, 64, k, stride, pad)
+    hout = (hin + 2 * pad - k) // stride + 1
+    assert d["hout"] == hout and d["wout"] == hout and d["tile"] in (32, 64, 128) and d["splits"] >= 1
+    live = sorted({ky * k + kx for oy in range(hout) for ox in range(hout) for ky in range(k) for kx in range(k)
+                   if 0 <= oy * stride - pad + ky < hin and 0 <= ox * stride - pad + kx < hin})
+    seen = {}
+    padded = 0
+    for ph in d["phases"]:
+        for my in range(ph["grid"][0]):
+            for mx in range(ph["grid"][1]):
+                o = (my + ph["off"][0], mx + ph["off"][1])
+                assert o not in seen and 0 <= o[0] < hout and 0 <= o[1] < hout
+                pairs = set()
+                for dy, dx, slot in ph["taps"]:
+                    iy, ix = my * stride + ph["origin"][0] + dy, mx * stride + ph["origin"][1] + dx
+                    if 0 <= iy < hin and 0 <= ix < hin:
+                        pairs.add((iy, ix, live[slot]))
+                    else:
+                        padded += 1
+                seen[o] = pairs
+    assert len(seen) == hout * hout
+    for (oy, ox), pairs in seen.items():
+        want = {(oy * stride - pad + ky, ox * stride - pad + kx, ky * k + kx) for ky in range(k) for kx in range(k)
+                if 0 <= oy * stride - pad + ky < hin and 0 <= ox * stride - pad + kx < hin}
+        assert pairs == want, (oy, ox)
+    if len(d["phases"]) > 1 or pad == 0:
+        assert padded == 0  # split into classes (or nothing to split): no tap ever reads padding
+
+
+@pytest.mark.parametrize("hin", [1, 2, 7, 16])
+def test_transposed_conv_phases(pkg, hin):
+    """ConvTranspose2d(k4, s2, p1) as sub-pixel phases x border classes: output pixel (oy, ox)
+    sums input (iy, ix) with kernel index ky = oy - 2 iy + 1 (and the same along x)."""
+    lib = importlib.import_module("gan-discovery-pso_amd._lib")
+    d = _describe(lib, 8, hin, 128, 64, 4, 2, 1, transposed=1)
+    assert d["hout"] == 2 * hin and len(d["phases"]) <= 16
+    k_of = [[1, 3], [2, 0]]
+    seen = {}
+    for ph in d["phases"]:
+        py, px = ph["off"][0] & 1, ph["off"][1] & 1
+        for my in range(ph["grid"][0]):
+            for mx in range(ph["grid"][1]):
+                o = (2 * my + ph["off"][0], 2 * mx + ph["off"][1])
+                assert o not in seen
+                pairs = set()
+                for dy, dx, slot in ph["taps"]:
+                    iy, ix = my + ph["origin"][0] + dy, mx + ph["origin"][1] + dx
+                    assert 0 <= iy < hin and 0 <= ix < hin  # border classes: never a padding tap
+                    pairs.add((iy, ix, k_of[py][slot // 2], k_of[px][slot % 2]))
+                seen[o] = pairs
+    assert len(seen) == 4 * hin * hin
+    for (oy, ox), pairs in seen.items():
+        want = {(iy, ix, oy - 2 * iy + 1, ox - 2 * ix + 1) for iy in range(hin) for ix in range(hin)
+                if 0 <= oy - 2 * iy + 1 < 4 and 0 <= ox - 2 * ix + 1 < 4}
+        assert pairs == want, (oy, ox)
+
+
+def test_conv_plan_shapes(pkg):
+    """Tile / split-K choices at the benchmark's batch: one workgroup per CU or more without
+    slabs where a 32-row tile gets there, split-K only below that."""
+    lib = importlib.import_module("gan-discovery-pso_amd._lib")
+    assert _describe(lib, 512, 7, 64, 64, 3, 1, 1)["tile"] == 64          # 392 tiles: plain 64x64
+    p = _describe(lib, 512, 2, 1024, 256, 1, 1, 0)                       # 128 tiles of 64x64 -> 256 of 32x64
+    assert p["tile"] == 32 and p["splits"] == 1
+    p = _describe(lib, 512, 1, 2048, 512, 1, 1, 0)                       # 128 tiles of 32x64 -> split-K
+    assert p["tile"] == 32 and p["splits"] == 2
+    assert _describe(lib, 8192, 7, 256, 256, 1, 1, 0)["tile"] == 128      # deep grid: 128x128
+    assert _describe(lib, 1, 7, 64, 64, 3, 1, 1)["splits"] >= 1
