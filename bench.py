@@ -120,8 +120,15 @@ def main():
 
     def run(first, count):
         dbg(f"run {first}..{first + count - 1}")
-        if comm is None:
+        if comm is None and not os.environ.get("GDPSO_BENCH_STEPWISE"):
             sw.iterate(first, count, spec, 1.496, 1.496, False, False, 1e-5, True, seed=42)
+        elif comm is None:  # the per-phase calls of the sharded loop without the collectives (host-overhead check)
+            for i in range(first, first + count):
+                sw.evaluate(i, spec)
+                sw.local_best(i)
+                sw.global_best(i, False, False, 1e-5)
+                sw.move(i, 1.496, 1.496, seed=42)
+                sw.mean_distance(i, sw.pos)
         else:
             deep = os.environ.get("GDPSO_BENCH_DEBUG") == "1"  # any other value: progress lines and the hang dump only
             for i in range(first, first + count):

@@ -513,16 +513,28 @@ class TorchComm:
 
     def all_gather(self, out: torch.Tensor, inp: torch.Tensor):
         # out [W, d+2] is the swarm's candidate table; inp is this rank's row of it
-        self._all_gather_flat(out.view(-1), inp.clone().view(-1))
+        # (the input is this rank's row of the output: a copy, so that the collective never aliases)
+        if getattr(self, "_rec", None) is None or self._rec.shape != inp.shape or self._rec.device != inp.device:
+            self._rec = torch.empty_like(inp)
+        self._rec.copy_(inp)
+        self._all_gather_flat(out.view(-1), self._rec.view(-1))
 
     def gather_positions(self, pos: torch.Tensor, n_global: int) -> torch.Tensor:
+        """Every rank's positions, in global particle order.  The returned tensor is a buffer of
+        this object that the next call overwrites."""
         n_max = -(-n_global // self.world)
-        pad = torch.zeros(n_max, pos.shape[1], dtype=pos.dtype, device=pos.device)
-        pad[:pos.shape[0]] = pos
-        allp = torch.empty(self.world * n_max, pos.shape[1], dtype=pos.dtype, device=pos.device)
-        self._all_gather_flat(allp.view(-1), pad.view(-1))
-        if n_global == self.world * n_max:
+        d = pos.shape[1]
+        key = (n_max, d, pos.dtype, pos.device)
+        if getattr(self, "_pos_key", None) != key:
+            self._pos_key = key
+            self._pos_all = torch.empty(self.world * n_max, d, dtype=pos.dtype, device=pos.device)
+            self._pos_pad = torch.zeros(n_max, d, dtype=pos.dtype, device=pos.device)
+        allp = self._pos_all
+        if n_global == self.world * n_max:  # equal shards: gather straight from the swarm state
+            self._all_gather_flat(allp.view(-1), pos.reshape(-1))
             return allp
+        self._pos_pad[:pos.shape[0]] = pos
+        self._all_gather_flat(allp.view(-1), self._pos_pad.view(-1))
         rows = []
         for r in range(self.world):
             lo, hi = shard_bounds(n_global, self.world, r)
