@@ -14,10 +14,11 @@
 // MFMA-issue bound: one ds_read_b128 per operand feeds four MFMAs (256 cycles).
 //
 // Tile: BM x BN outputs per 256-thread workgroup, two LDS buffers, register prefetch of the
-// next K-tile, one barrier per K-tile, LDS-staged 16-byte epilogue.  Three shapes: 128x128 and
-// 64x64 (four waves as 2x2, K-tiles of 32) and 32x64 (two waves side by side, the other two
-// take the second half of every 64-wide K-tile; halves added through LDS), which doubles the
-// workgroups of the small-M layers of the late ResNet stages.  Layers that still have fewer
+// next K-tile, one barrier per K-tile, LDS-staged 16-byte epilogue.  Four shapes: 128x128 and
+// 64x64 (four waves as 2x2, K-tiles of 32), 32x64 (two waves side by side, the other two take
+// the second half of every 64-wide K-tile) and 32x32 (each wave a quarter of every 128-wide
+// K-tile); the K parts are added through LDS in a fixed order.  Each step down doubles the
+// workgroups of the small-M layers of the late ResNet stages without split-K slabs.  Layers that still have fewer
 // workgroups than CUs split K over blockIdx.z into fp32 slabs summed by splitk_reduce_kernel.
 //
 // A layer is a list of phases, each an output sub-grid with its own tap list.  Padded
@@ -195,7 +196,8 @@ __device__ __forceinline__ void conv_store_tile(const ConvKArgs &a, float *lds, 
 }
 
 // BM x BN output tile, K-tiles of BKT floats.  KW = 1: the four waves form a 2 x 2 grid over the
-// tile.  KW = 2 (BM = 32): two waves side by side cover the tile and the other two take the
+// tile.  KW = 4 (32 x 32): every wave takes a quarter of each K-tile of the one 32 x 32 block.
+// KW = 2 (BM = 32): two waves side by side cover the tile and the other two take the
 // second half of every K-tile; the two halves are added through LDS before the epilogue.  That
 // shape doubles the number of workgroups of a small-M layer without split-K slabs.
 template <int BM, int BN, int BKT, int KW, bool FUSE = false>
@@ -204,7 +206,8 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, cons
     static_assert(BKT / KW == 32, "every wave consumes 32 k per K-tile");
     static_assert(KW == 1 || BM == 32, "the K-split layout is for 32-row tiles");
     constexpr int LDA = BKT + 4;  // 144- or 272-byte rows: ds_read_b128 of consecutive rows is conflict-free
-    constexpr int WM = KW == 1 ? BM / 64 : 1, WN = KW == 1 ? BN / 64 : BN / 64;  // 32x32 MFMA blocks per wave
+    static_assert(KW == 1 || BN * KW == 128, "K-split layouts: 32x64 over two wave pairs, 32x32 over four waves");
+    constexpr int WM = KW == 1 ? BM / 64 : 1, WN = KW == 1 ? BN / 64 : 1;  // 32x32 MFMA blocks per wave
     constexpr int RP = 256 / (BKT / 4);        // rows covered by one loader pass
     constexpr int PA = BM / RP, PB = BN / RP;  // loader passes
     constexpr int LDS_FLOATS = 2 * (BM + BN) * LDA;
@@ -213,7 +216,7 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, cons
     float *sB = lds + 2 * BM * LDA;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = KW == 1 ? wave >> 1 : 0, wc = wave & 1, kh = KW == 1 ? 0 : wave >> 1;
+    const int wr = KW == 1 ? wave >> 1 : 0, wc = KW == 4 ? 0 : wave & 1, kh = KW == 1 ? 0 : (KW == 2 ? wave >> 1 : wave);
     const int l31 = lane & 31, half = lane >> 5;
 
     // Workgroups b and b+8 share an XCD (and its L2): give each XCD a contiguous run of
@@ -453,7 +456,7 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, cons
     // in LDS (the K loop's last barrier has retired every operand read).
     constexpr int LDC = BN + 4;
     float *sC = lds;
-    if (KW == 1 || kh == 1) {
+    if (KW == 1) {
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -461,17 +464,26 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, cons
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     sC[(wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDC + wc * (BN / 2) + j * 32 + l31] = acc[i][j][r];
-    }
-    if (KW == 2) {  // first K half + second K half, always in that order
+    } else {
+        // K-split layouts: the waves of K part q > 0 park their 32x32 block in region q - 1, the wave
+        // of part 0 adds them in the order q = 1, 2, ... and lays out the tile (regions of BM x LDC floats)
+        constexpr int REGION = BM * LDC;
+        static_assert(LDS_FLOATS >= KW * REGION + 4, "room for the partial tiles");
+        if (kh > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                sC[kh * REGION + ((r & 3) + 8 * (r >> 2) + 4 * half) * LDC + wc * 32 + l31] = acc[0][0][r];
+        }
         __syncthreads();
         if (kh == 0) {
 #pragma unroll
-            for (int j = 0; j < WN; ++j)
+            for (int r = 0; r < 16; ++r) {
+                const int e = ((r & 3) + 8 * (r >> 2) + 4 * half) * LDC + wc * 32 + l31;
+                float v = acc[0][0][r];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float *c = &sC[((r & 3) + 8 * (r >> 2) + 4 * half) * LDC + wc * (BN / 2) + j * 32 + l31];
-                    *c = acc[0][j][r] + *c;
-                }
+                for (int q = 1; q < KW; ++q) v += sC[q * REGION + e];
+                sC[e] = v;
+            }
         }
     }
     __syncthreads();
@@ -580,9 +592,10 @@ static long max_ktot(const ConvLayer &L) {
 // split-K only pays when the unsplit grid has fewer workgroups than CUs; then just enough
 // splits to give every CU one workgroup.
 // L.tile names the kernel shape: 128 -> 128x128, 64 -> 64x64, 32 -> 32 rows x 64 columns with the
-// K-tile split over wave pairs.
-static int tile_bm(int tile) { return tile; }
-static int tile_bn(int tile) { return tile == 32 ? 64 : tile; }
+// K-tile split over wave pairs, 16 -> 32x32 with the K-tile split over the four waves.
+constexpr int TILE_32x32 = 16;
+static int tile_bm(int tile) { return tile == TILE_32x32 ? 32 : tile; }
+static int tile_bn(int tile) { return tile == 32 ? 64 : tile == TILE_32x32 ? 32 : tile; }
 
 static long m_tiles(const ConvLayer &L, int n_images, int tile) {
     long t = 0;
@@ -600,6 +613,8 @@ int plan_conv(ConvLayer &L, int n_images, int num_cus) {
     // at most one 64x64 tile per CU: 32-row tiles double the workgroups without slabs (measured:
     // a gain up to 256 tiles, a loss at 392)
     if (L.tile == 64 && g_allow_tile32 && L.cin % 64 == 0 && m_tiles(L, n_images, 64) * (L.cout / 64) <= (long)num_cus) L.tile = 32;
+    // still at most one workgroup per CU: 32x32 tiles with the K-tile split four ways double them again
+    if (L.tile == 32 && L.cin % 128 == 0 && m_tiles(L, n_images, 32) * (L.cout / 64) <= (long)num_cus) L.tile = TILE_32x32;
     const long tiles = m_tiles(L, n_images, L.tile) * (L.cout / tile_bn(L.tile));
     const long ktot = max_ktot(L);
     int splits = 1;
@@ -654,6 +669,7 @@ static int conv_args(const ConvLayer &L, int n_images, const float *in, const fl
     if (a.slab * 4 >= (1L << 31)) return fail(GDPSO_ERR_ARG, "conv: output larger than 2 GiB");
     if (tiles_total >= (1L << 30) || (long)n_images * L.hout * L.wout >= (1L << 31)) return fail(GDPSO_ERR_ARG, "conv: too many rows");
     if (L.tile == 32 && L.cin % 64 != 0) return fail(GDPSO_ERR_ARG, "conv: the 32-row tile needs cin to be a multiple of 64");
+    if (L.tile == TILE_32x32 && L.cin % 128 != 0) return fail(GDPSO_ERR_ARG, "conv: the 32x32 tile needs cin to be a multiple of 128");
     *tiles = tiles_total;
     return GDPSO_OK;
 }
@@ -687,8 +703,10 @@ int launch_conv(const ConvLayer &L, hipStream_t stream, int n_images, const floa
         GDPSO_LAUNCH((conv_gemm_kernel<128, 128, 32, 1>))
     } else if (L.tile == 64) {
         GDPSO_LAUNCH((conv_gemm_kernel<64, 64, 32, 1>))
-    } else {
+    } else if (L.tile == 32) {
         GDPSO_LAUNCH((conv_gemm_kernel<32, 64, 64, 2>))
+    } else {
+        GDPSO_LAUNCH((conv_gemm_kernel<32, 32, 128, 4>))
     }
 #undef GDPSO_LAUNCH
     if (timed) {
@@ -746,7 +764,7 @@ int launch_conv_then_1x1(const ConvLayer &La, const ConvLayer &Lb, hipStream_t s
 // to two launches when the planner gave them different shapes or either is split.
 int launch_conv_pair(const ConvLayer &La, const ConvLayer &Lb, hipStream_t stream, int n_images, const float *in,
                      float *out_a, float *out_b, float *splitk_ws) {
-    if (!g_pair_launch || La.tile != Lb.tile || La.splits != 1 || Lb.splits != 1) {
+    if (!g_pair_launch || La.tile != Lb.tile || La.tile == TILE_32x32 || La.splits != 1 || Lb.splits != 1) {
         int rc = launch_conv(La, stream, n_images, in, nullptr, out_a, splitk_ws);
         if (rc) return rc;
         return launch_conv(Lb, stream, n_images, in, nullptr, out_b, splitk_ws);
@@ -868,7 +886,9 @@ extern "C" int gdpso_conv_probe(int n_images, int hin, int cin, int cout, int ks
                                 int splits, int with_res, int reps, double *avg_us, int *tile_used, int *splits_used) {
     using namespace gdpso;
     GDPSO_REQUIRE(n_images > 0 && hin > 0 && cin % 32 == 0 && cout % 64 == 0 && reps > 0 && avg_us, "conv_probe: bad argument");
-    GDPSO_REQUIRE(tile == 0 || tile == 64 || (tile == 32 && cin % 64 == 0) || (tile == 128 && cout % 128 == 0), "conv_probe: bad tile");
+    GDPSO_REQUIRE(tile == 0 || tile == 64 || (tile == 32 && cin % 64 == 0) || (tile == TILE_32x32 && cin % 128 == 0) ||
+                      (tile == 128 && cout % 128 == 0),
+                  "conv_probe: bad tile");
     std::vector<float> w((size_t)cout * cin * ksize * ksize), packed, sc(cout, 1.f), sh(cout, 0.1f);
     uint32_t st = 12345u;
     auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 65536.f - 0.5f; };

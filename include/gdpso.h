@@ -275,7 +275,9 @@ int gdpso_conv_plan_describe(int n_images, int hin, int cin, int cout, int ksize
 
 /* No counterpart in the reference: times one ksize x ksize convolution layer in isolation
  * on random data (allocates and frees its own buffers; a development / tuning aid).
- * tile (0 = planner's choice, 32, 64 or 128) and splits (0 = planner's choice) override the launch plan. */
+ * tile (0 = planner's choice; 128 = 128x128, 64 = 64x64, 32 = 32x64 with the K-tile split over two wave
+ * pairs, 16 = 32x32 with the K-tile split over the four waves) and splits (0 = planner's choice) override
+ * the launch plan. */
 int gdpso_conv_probe(int n_images, int hin, int cin, int cout, int ksize, int stride, int pad, int tile,
                      int splits, int with_res, int reps, double *avg_us, int *tile_used, int *splits_used);
 

@@ -111,7 +111,7 @@ def test_conv_phases_cover_exactly_the_in_range_taps(pkg, hin, k, stride, pad):
     lib = importlib.import_module("gan-discovery-pso_amd._lib")
     d = _describe(lib, 8, hin, 64, 64, k, stride, pad)
     hout = (hin + 2 * pad - k) // stride + 1
-    assert d["hout"] == hout and d["wout"] == hout and d["tile"] in (32, 64, 128) and d["splits"] >= 1
+    assert d["hout"] == hout and d["wout"] == hout and d["tile"] in (16, 32, 64, 128) and d["splits"] >= 1
     live = sorted({ky * k + kx for oy in range(hout) for ox in range(hout) for ky in range(k) for kx in range(k)
                    if 0 <= oy * stride - pad + ky < hin and 0 <= ox * stride - pad + kx < hin})
     seen = {}
@@ -167,13 +167,18 @@ def test_transposed_conv_phases(pkg, hin):
 
 
 def test_conv_plan_shapes(pkg):
-    """Tile / split-K choices at the benchmark's batch: one workgroup per CU or more without
-    slabs where a 32-row tile gets there, split-K only below that."""
+    """Tile / split-K choices at the benchmark's batch (tile codes: 128 = 128x128, 64 = 64x64,
+    32 = 32x64 over two wave pairs, 16 = 32x32 over four waves): smaller tiles until there is more
+    than one workgroup per CU, split-K only below that."""
     lib = importlib.import_module("gan-discovery-pso_amd._lib")
     assert _describe(lib, 512, 7, 64, 64, 3, 1, 1)["tile"] == 64          # 392 tiles: plain 64x64
-    p = _describe(lib, 512, 2, 1024, 256, 1, 1, 0)                       # 128 tiles of 64x64 -> 256 of 32x64
+    p = _describe(lib, 512, 4, 512, 128, 1, 1, 0)                        # 256 tiles of 64x64 -> 512 of 32x64
     assert p["tile"] == 32 and p["splits"] == 1
-    p = _describe(lib, 512, 1, 2048, 512, 1, 1, 0)                       # 128 tiles of 32x64 -> split-K
-    assert p["tile"] == 32 and p["splits"] == 2
+    p = _describe(lib, 512, 2, 1024, 256, 1, 1, 0)                       # 256 tiles of 32x64 -> 512 of 32x32
+    assert p["tile"] == 16 and p["splits"] == 1
+    p = _describe(lib, 512, 1, 2048, 512, 1, 1, 0)                       # 128 tiles of 32x64 -> 256 of 32x32, no slabs
+    assert p["tile"] == 16 and p["splits"] == 1
+    p = _describe(lib, 128, 1, 2048, 512, 1, 1, 0)                       # 64 tiles of 32x32 -> split-K
+    assert p["tile"] == 16 and p["splits"] == 4
     assert _describe(lib, 8192, 7, 256, 256, 1, 1, 0)["tile"] == 128      # deep grid: 128x128
     assert _describe(lib, 1, 7, 64, 64, 3, 1, 1)["splits"] >= 1

@@ -45,10 +45,10 @@ def main():
         line = f"{name:7s} M={args.n * hout * hout:6d} K={cin * k * k:5d} N={cout:5d}  plan t{t0} s{s0}: {us0:6.1f}us {flops / us0 / 1e6:6.1f}TF |"
         best = (us0, t0, s0)
         if not args.quick:
-            for tile in (32, 64, 128):
-                if (tile == 128 and cout % 128) or (tile == 32 and cin % 64):
+            for tile in (16, 32, 64):
+                if (tile == 16 and cin % 128) or (tile == 32 and cin % 64):
                     continue
-                for splits in (1, 2, 4, 8):
+                for splits in (1, 2, 4):
                     if splits > 1 and cin * k * k // splits < 64:
                         continue
                     us, _, _ = probe(args.n, hin, cin, cout, k, stride, pad, tile, splits, res)
