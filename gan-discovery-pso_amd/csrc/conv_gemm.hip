@@ -91,6 +91,19 @@ struct PhaseInfo {
 constexpr int MAX_CIN = 4096;
 __device__ __attribute__((aligned(128))) float g_zero_page[MAX_CIN + 32] = {};
 
+#ifdef GDPSO_STAMPS
+// Diagnostic build only (tools/stamp_probe.py): per-workgroup time stamps of the tile code.
+__device__ unsigned long long *g_stamps = nullptr;
+#define GDPSO_STAMP(SLOT)                                                                   \
+    if (g_stamps && threadIdx.x == 0) {                                                     \
+        g_stamps[(size_t)blockIdx.x * 8 + (SLOT)] = __builtin_amdgcn_s_memtime();           \
+        if ((SLOT) == 0) g_stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime(); \
+        if ((SLOT) == 3) g_stamps[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime(); \
+    }
+#else
+#define GDPSO_STAMP(SLOT)
+#endif
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == ACT_RELU) return v > 0.f ? v : 0.f;
     if (act == ACT_LEAKY02) return v > 0.f ? v : 0.2f * v;
@@ -215,6 +228,7 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, cons
     float *sA = lds;
     float *sB = lds + 2 * BM * LDA;
 
+    GDPSO_STAMP(0)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = KW == 1 ? wave >> 1 : 0, wc = KW == 4 ? 0 : wave & 1, kh = KW == 1 ? 0 : (KW == 2 ? wave >> 1 : wave);
     const int l31 = lane & 31, half = lane >> 5;
@@ -337,6 +351,7 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, cons
         GDPSO_SSTORE(0)
     }
     __syncthreads();
+    GDPSO_STAMP(1)
     int buf = 0;
     for (int kt = kbeg; kt < kend; kt += BKT) {
         const bool more = kt + BKT < kend;
@@ -376,6 +391,7 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, cons
 #undef GDPSO_GLOAD
 #undef GDPSO_SSTORE
 #undef GDPSO_LOADFRAG
+    GDPSO_STAMP(2)
 
     if constexpr (FUSE) {
         // This layer's 64 x 64 tile, activated, becomes the A operand (K = 64) of the next layer;
@@ -488,6 +504,10 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, cons
     }
     __syncthreads();
     conv_store_tile<BM, BN>(a, lds, LDS_FLOATS, tid, m0, n0, sp, tile, P);
+#ifdef GDPSO_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have left the CU
+    GDPSO_STAMP(3)
+#endif
 }
 
 template <int BM, int BN, int BKT, int KW>
@@ -836,6 +856,13 @@ extern "C" int gdpso_conv_timing_end(double *total_ms, int *launches, double *fl
     if (flops) *flops = g_timing.flops;
     return GDPSO_OK;
 }
+
+#ifdef GDPSO_STAMPS
+extern "C" int gdpso_conv_stamps_set(void *device_buffer) {
+    GDPSO_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gdpso::g_stamps), &device_buffer, sizeof(void *)));
+    return GDPSO_OK;
+}
+#endif
 
 extern "C" double gdpso_conv_timing_bytes(void) { return gdpso::g_timing.bytes; }
 extern "C" double gdpso_conv_timing_executed_flops(void) { return gdpso::g_timing.executed; }
