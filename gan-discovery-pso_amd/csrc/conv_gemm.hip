@@ -352,41 +352,42 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, cons
     }
     __syncthreads();
     GDPSO_STAMP(1)
-    int buf = 0;
-    for (int kt = kbeg; kt < kend; kt += BKT) {
-        const bool more = kt + BKT < kend;
-        if (more) GDPSO_GLOAD()
-        const float *pa = sA + buf * BM * LDA + (wr * (BM / 2) + l31) * LDA + half * 4 + kh * 32;
-        const float *pb = sB + buf * BN * LDA + (wc * (BN / 2) + l31) * LDA + half * 4 + kh * 32;
-        // Within a K-tile the 32 k's are consumed in a permuted order: MFMA step s of group g
-        // takes k = 8g + 4*half + s from both operands, so each lane's four steps are one
-        // 16-byte LDS read.  The sum over k is the same set of products.  The fragments of
-        // group g+1 are read while the MFMAs of group g issue.
-        f32x4 av[2][WM], bv[2][WN];
-        GDPSO_LOADFRAG(0, 0)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (g < 3) GDPSO_LOADFRAG((g + 1) & 1, g + 1)
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int i = 0; i < WM; ++i)
-#pragma unroll
-                    for (int j = 0; j < WN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1][i][s], bv[g & 1][j][s], acc[i][j], 0, 0, 0);
-        }
-        // pin the order: reads of group g+1 ahead of the MFMAs of group g (0x100 = DS read, 0x8 = MFMA)
-        __builtin_amdgcn_sched_group_barrier(0x100, WM + WN, 0);
-#pragma unroll
-        for (int g = 0; g < 3; ++g) {
-            __builtin_amdgcn_sched_group_barrier(0x100, WM + WN, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * WM * WN, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * WM * WN, 0);
-        if (more) GDPSO_SSTORE(buf ^ 1)
-        __syncthreads();
-        buf ^= 1;
+    // One K-tile.  Within it the 32 k's of a wave are consumed in a permuted order: MFMA step s of
+    // group g takes k = 8g + 4*half + s from both operands, so each lane's four steps are one
+    // 16-byte LDS read; the sum over k is the same set of products.  The fragments of group g+1
+    // are read while the MFMAs of group g issue, and (MORE) the prefetched next K-tile moves from
+    // registers to the other LDS buffer ahead of the last group, in the shadow of the MFMAs that
+    // are still executing, instead of after them.  The sched_group_barrier sequence pins that
+    // order (0x100 = DS read, 0x200 = DS write, 0x008 = MFMA).
+#define GDPSO_KSTEP(MORE)                                                                                       \
+    {                                                                                                           \
+        if (MORE) GDPSO_GLOAD()                                                                                 \
+        const float *pa = sA + buf * BM * LDA + (wr * (BM / 2) + l31) * LDA + half * 4 + kh * 32;               \
+        const float *pb = sB + buf * BN * LDA + (wc * (BN / 2) + l31) * LDA + half * 4 + kh * 32;               \
+        f32x4 av[2][WM], bv[2][WN];                                                                             \
+        GDPSO_LOADFRAG(0, 0)                                                                                    \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                         \
+            if (g < 3) GDPSO_LOADFRAG((g + 1) & 1, g + 1)                                                       \
+            if (g == 3 && (MORE)) GDPSO_SSTORE(buf ^ 1)                                                         \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                       \
+                _Pragma("unroll") for (int i = 0; i < WM; ++i)                                                  \
+                    _Pragma("unroll") for (int j = 0; j < WN; ++j)                                              \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1][i][s], bv[g & 1][j][s], acc[i][j], 0, 0, 0); \
+        }                                                                                                       \
+        __builtin_amdgcn_sched_group_barrier(0x100, WM + WN, 0);                                                \
+        _Pragma("unroll") for (int g = 0; g < 3; ++g) {                                                         \
+            __builtin_amdgcn_sched_group_barrier(0x100, WM + WN, 0);                                            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * WM * WN, 0);                                        \
+        }                                                                                                       \
+        if (MORE) __builtin_amdgcn_sched_group_barrier(0x200, PA + PB, 0);                                      \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * WM * WN, 0);                                            \
+        __syncthreads();                                                                                        \
+        buf ^= 1;                                                                                               \
     }
+    int buf = 0;
+    for (int kt = kbeg; kt + BKT < kend; kt += BKT) GDPSO_KSTEP(true)
+    if (kbeg < kend) GDPSO_KSTEP(false)
+#undef GDPSO_KSTEP
 #undef GDPSO_SET_TAP
 #undef GDPSO_GLOAD
 #undef GDPSO_SSTORE
