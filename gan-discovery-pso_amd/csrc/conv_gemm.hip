@@ -65,7 +65,8 @@ struct ConvKArgs {
     int act, splits;
     int tiles_n;
     long slab;  // elements per split-K slab
-    int tile_end[MAX_PHASES];  // running count of M-tiles up to and including each phase (INT_MAX past the last)
+    int phase_tiles[MAX_PHASES];  // tiles (M-tiles x column tiles) of each phase
+    int phase_end[MAX_PHASES];    // running sum over phases of ceil(phase_tiles / 8) (INT_MAX past the last)
 };
 
 // A 1x1 convolution over the same pixels, applied to this layer's output tile before it leaves
@@ -214,7 +215,7 @@ __device__ __forceinline__ void conv_store_tile(const ConvKArgs &a, float *lds, 
 // second half of every K-tile; the two halves are added through LDS before the epilogue.  That
 // shape doubles the number of workgroups of a small-M layer without split-K slabs.
 template <int BM, int BN, int BKT, int KW, bool FUSE = false>
-__device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, const int nt, float *lds, const FuseArgs *fuse = nullptr) {
+__device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, float *lds, const FuseArgs *fuse = nullptr) {
     static_assert(!FUSE || (BM == 64 && BN == 64 && KW == 1), "the fused tail is written for the 64x64 tile");
     static_assert(BKT / KW == 32, "every wave consumes 32 k per K-tile");
     static_assert(KW == 1 || BM == 32, "the K-split layout is for 32-row tiles");
@@ -233,21 +234,25 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, cons
     const int wr = KW == 1 ? wave >> 1 : 0, wc = KW == 4 ? 0 : wave & 1, kh = KW == 1 ? 0 : (KW == 2 ? wave >> 1 : wave);
     const int l31 = lane & 31, half = lane >> 5;
 
-    // Workgroups b and b+8 share an XCD (and its L2): give each XCD a contiguous run of
-    // tiles, so tiles that share input rows or weight columns hit the same L2.
-    const int xq = nt >> 3, xr = nt & 7;
+    // Workgroups b and b+8 share an XCD (and its L2).  Each XCD gets a contiguous eighth of the
+    // tiles of EVERY phase, phase after phase: contiguous, so that tiles that share input rows or
+    // weight columns hit the same L2; of every phase, because phases differ in cost (a border
+    // class has fewer taps than the interior) and an XCD holding only interior tiles would finish
+    // last.  A phase's tile count is rounded up to a multiple of 8; the surplus workgroups exit.
     const int xcd = bx & 7, slot = bx >> 3;
-    const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + slot;
-    const int tmg = tile / a.tiles_n, tn = tile - tmg * a.tiles_n;
-    // phase of this M-tile: the last one whose predecessors end at or before it
-    int ph = 0, tm_base = 0;
+    int ph = 0, base = 0;
 #pragma unroll
     for (int p = 0; p < MAX_PHASES - 1; ++p)
-        if (tmg >= a.tile_end[p]) {
+        if (slot >= a.phase_end[p]) {
             ph = p + 1;
-            tm_base = a.tile_end[p];
+            base = a.phase_end[p];
         }
-    const int m0 = (tmg - tm_base) * BM, n0 = tn * BN;
+    const int per_xcd = a.phase_end[ph] - base;
+    const int idx = xcd * per_xcd + (slot - base);
+    if (idx >= a.phase_tiles[ph]) return;
+    const int tile = bx;
+    const int tml = idx / a.tiles_n, tn = idx - tml * a.tiles_n;
+    const int m0 = tml * BM, n0 = tn * BN;
     const int sp = blockIdx.z;
     const int *tab = a.table + ph * PHASE_TABLE_INTS;
     const int ntaps = tab[0];
@@ -514,31 +519,28 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, cons
 template <int BM, int BN, int BKT, int KW>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * (BKT + 4)];
-    conv_tile<BM, BN, BKT, KW>(a, blockIdx.x, gridDim.x, lds);
+    conv_tile<BM, BN, BKT, KW>(a, blockIdx.x, lds);
 }
 
 // A convolution with 64 output channels followed by a 1x1 convolution, one launch: conv2 + conv3
 // of the first-stage bottleneck blocks.  The intermediate never leaves the workgroup.
 __global__ __launch_bounds__(256, 2) void conv_gemm_fused_kernel(const ConvKArgs a, const FuseArgs f) {
     __shared__ __attribute__((aligned(16))) float lds[3 * 64 * 68];
-    conv_tile<64, 64, 32, 1, true>(a, blockIdx.x, gridDim.x, lds, &f);
+    conv_tile<64, 64, 32, 1, true>(a, blockIdx.x, lds, &f);
 }
 
-// Two independent layers in one grid (same tile shape, no split-K): the first tiles_a_pad
-// workgroups (a multiple of 8, so that both layers see workgroup index & 7 == XCD) belong to
-// layer a, the rest to layer b.  Used for identity_downsample + conv1 of a bottleneck block,
-// which read the same input: one launch, one fill and drain, and the tail of one layer overlaps
-// the other.
+// Two independent layers in one grid (same tile shape, no split-K): the first tiles_a workgroups
+// (a multiple of 8, so that both layers see workgroup index & 7 == XCD) belong to layer a, the
+// rest to layer b.  Used for identity_downsample + conv1 of a bottleneck block, which read the
+// same input: one launch, one fill and drain, and the tail of one layer overlaps the other.
 template <int BM, int BN, int BKT, int KW>
-__global__ __launch_bounds__(256, 2) void conv_gemm_pair_kernel(const ConvKArgs a, const ConvKArgs b, int tiles_a,
-                                                                int tiles_a_pad) {
+__global__ __launch_bounds__(256, 2) void conv_gemm_pair_kernel(const ConvKArgs a, const ConvKArgs b, int tiles_a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * (BKT + 4)];
     // two copies of the tile code, each reading its own kernel arguments straight from SGPRs
-    if ((int)blockIdx.x < tiles_a_pad) {
-        if ((int)blockIdx.x < tiles_a) conv_tile<BM, BN, BKT, KW>(a, blockIdx.x, tiles_a, lds);
-    } else {
-        conv_tile<BM, BN, BKT, KW>(b, blockIdx.x - tiles_a_pad, (int)gridDim.x - tiles_a_pad, lds);
-    }
+    if ((int)blockIdx.x < tiles_a)
+        conv_tile<BM, BN, BKT, KW>(a, blockIdx.x, lds);
+    else
+        conv_tile<BM, BN, BKT, KW>(b, blockIdx.x - tiles_a, lds);
 }
 
 // Sums the split-K slabs and applies the epilogue.  One float4 (4 channels) per thread.
@@ -664,21 +666,25 @@ int conv_splitk_prepare(hipStream_t stream, float *splitk_ws) {
 
 // Fills the kernel arguments of one layer; returns its number of workgroups per split through *tiles.
 static int conv_args(const ConvLayer &L, int n_images, const float *in, const float *res, float *out, float *splitk_ws,
-                     ConvKArgs &a, long *tiles, bool *fused_reduce) {
+                     ConvKArgs &a, long *grid_x, bool *fused_reduce) {
     a.in = in; a.wt = L.wt; a.scale = L.scale; a.shift = L.shift; a.res = res; a.out = out;
     const long tiles_m = m_tiles(L, n_images, L.tile);
     const long tiles_total = tiles_m * (L.cout / tile_bn(L.tile));
-    // in-kernel (last-arriver) reduction up to GDPSO_SPLITK_FUSED_MAX splits (default: off)
-    *fused_reduce = L.splits > 1 && L.splits <= g_fused_max_splits && (size_t)tiles_total * sizeof(int) <= SPLITK_COUNTER_BYTES;
-    a.part = L.splits > 1 ? splitk_ws + SPLITK_COUNTER_BYTES / sizeof(float) : nullptr;
-    a.counters = *fused_reduce ? (int *)splitk_ws : nullptr;
     a.table = L.table;
     a.n_images = n_images;
-    long run = 0;
+    long per_xcd = 0;
     for (int p = 0; p < MAX_PHASES; ++p) {
-        if (p < L.nphase) run += ceil_div((long)n_images * L.phase[p].hm * L.phase[p].wm, tile_bm(L.tile));
-        a.tile_end[p] = p < L.nphase ? (int)run : 0x7fffffff;
+        a.phase_tiles[p] = p < L.nphase ? (int)(ceil_div((long)n_images * L.phase[p].hm * L.phase[p].wm, tile_bm(L.tile)) *
+                                                (L.cout / tile_bn(L.tile)))
+                                        : 0;
+        if (p < L.nphase) per_xcd += ceil_div(a.phase_tiles[p], 8);
+        a.phase_end[p] = p < L.nphase ? (int)per_xcd : 0x7fffffff;
     }
+    *grid_x = 8 * per_xcd;
+    // in-kernel (last-arriver) reduction up to GDPSO_SPLITK_FUSED_MAX splits (default: off); one counter per workgroup index
+    *fused_reduce = L.splits > 1 && L.splits <= g_fused_max_splits && (size_t)*grid_x * sizeof(int) <= SPLITK_COUNTER_BYTES;
+    a.part = L.splits > 1 ? splitk_ws + SPLITK_COUNTER_BYTES / sizeof(float) : nullptr;
+    a.counters = *fused_reduce ? (int *)splitk_ws : nullptr;
     a.hin = L.hin; a.win = L.win; a.cin = L.cin;
     a.cout = L.cout; a.hout = L.hout; a.wout = L.wout;
     a.in_stride = L.in_stride; a.out_mul = L.out_mul;
@@ -691,7 +697,6 @@ static int conv_args(const ConvLayer &L, int n_images, const float *in, const fl
     if (tiles_total >= (1L << 30) || (long)n_images * L.hout * L.wout >= (1L << 31)) return fail(GDPSO_ERR_ARG, "conv: too many rows");
     if (L.tile == 32 && L.cin % 64 != 0) return fail(GDPSO_ERR_ARG, "conv: the 32-row tile needs cin to be a multiple of 64");
     if (L.tile == TILE_32x32 && L.cin % 128 != 0) return fail(GDPSO_ERR_ARG, "conv: the 32x32 tile needs cin to be a multiple of 128");
-    *tiles = tiles_total;
     return GDPSO_OK;
 }
 
@@ -796,16 +801,15 @@ int launch_conv_pair(const ConvLayer &La, const ConvLayer &Lb, hipStream_t strea
     int rc;
     if ((rc = conv_args(La, n_images, in, nullptr, out_a, splitk_ws, a, &ta, &fa))) return rc;
     if ((rc = conv_args(Lb, n_images, in, nullptr, out_b, splitk_ws, b, &tb, &fb))) return rc;
-    const int ta_pad = (int)((ta + 7) / 8 * 8);
-    dim3 grid((unsigned)(ta_pad + tb), 1, 1);
+    dim3 grid((unsigned)(ta + tb), 1, 1);
     const bool timed = g_timing.on && g_timing.used + 2 <= g_timing.events.size();
     hipEvent_t e0 = timed ? g_timing.events[g_timing.used] : nullptr;
     hipEvent_t e1 = timed ? g_timing.events[g_timing.used + 1] : nullptr;
 #define GDPSO_LAUNCH(KERNEL)                                                                          \
     if (timed)                                                                                        \
-        hipExtLaunchKernelGGL((KERNEL), grid, dim3(256), 0, stream, e0, e1, 0, a, b, (int)ta, ta_pad); \
+        hipExtLaunchKernelGGL((KERNEL), grid, dim3(256), 0, stream, e0, e1, 0, a, b, (int)ta);         \
     else                                                                                              \
-        hipLaunchKernelGGL((KERNEL), grid, dim3(256), 0, stream, a, b, (int)ta, ta_pad);
+        hipLaunchKernelGGL((KERNEL), grid, dim3(256), 0, stream, a, b, (int)ta);
     if (La.tile == 128) {
         GDPSO_LAUNCH((conv_gemm_pair_kernel<128, 128, 32, 1>))
     } else if (La.tile == 64) {
