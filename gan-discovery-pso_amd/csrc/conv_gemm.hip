@@ -67,6 +67,8 @@ struct ConvKArgs {
     long slab;  // elements per split-K slab
     int phase_tiles[MAX_PHASES];  // tiles (M-tiles x column tiles) of each phase
     int phase_end[MAX_PHASES];    // running sum over phases of ceil(phase_tiles / 8) (INT_MAX past the last)
+    int per_xcd;                  // workgroups of this layer per XCD (= the last phase_end)
+    int snake;                    // CUs per XCD when the second round of workgroups is dealt in reverse, else 0
 };
 
 // A 1x1 convolution over the same pixels, applied to this layer's output tile before it leaves
@@ -99,6 +101,9 @@ __device__ unsigned long long *g_stamps = nullptr;
     if (g_stamps && threadIdx.x == 0) {                                                     \
         g_stamps[(size_t)blockIdx.x * 8 + (SLOT)] = __builtin_amdgcn_s_memtime();           \
         if ((SLOT) == 0) g_stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime(); \
+        if ((SLOT) == 0)                                                                    \
+            g_stamps[(size_t)blockIdx.x * 8 + 5] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | /* HW_REG_HW_ID */ \
+                                                   ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32); /* HW_REG_XCC_ID */ \
         if ((SLOT) == 3) g_stamps[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime(); \
     }
 #else
@@ -239,7 +244,12 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
     // weight columns hit the same L2; of every phase, because phases differ in cost (a border
     // class has fewer taps than the interior) and an XCD holding only interior tiles would finish
     // last.  A phase's tile count is rounded up to a multiple of 8; the surplus workgroups exit.
-    const int xcd = bx & 7, slot = bx >> 3;
+    const int xcd = bx & 7;
+    int slot = bx >> 3;
+    // An XCD deals its workgroups round-robin to its CUs: with two per CU and phases in order of
+    // decreasing cost, CU i would get the i-th heaviest and the (i + CUs)-th heaviest.  Dealing the
+    // second round from the light end pairs heavy with light.
+    if (a.snake && slot >= a.snake) slot = a.per_xcd - 1 - (slot - a.snake);
     int ph = 0, base = 0;
 #pragma unroll
     for (int p = 0; p < MAX_PHASES - 1; ++p)
@@ -589,6 +599,16 @@ static bool g_allow_tile32 = [] {
     return e ? e[0] != '0' : true;
 }();
 
+static bool g_snake = [] {
+    const char *e = getenv("GDPSO_CONV_SNAKE");
+    return e ? e[0] != '0' : true;
+}();
+static int g_cus_per_xcd = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return std::max(1, cus / 8);
+}();
+
 static bool g_fuse_1x1 = [] {
     const char *e = getenv("GDPSO_CONV_FUSE_1X1");
     return e ? e[0] != '0' : true;
@@ -681,6 +701,8 @@ static int conv_args(const ConvLayer &L, int n_images, const float *in, const fl
         a.phase_end[p] = p < L.nphase ? (int)per_xcd : 0x7fffffff;
     }
     *grid_x = 8 * per_xcd;
+    a.per_xcd = (int)per_xcd;
+    a.snake = (g_snake && L.nphase > 1 && per_xcd > g_cus_per_xcd && per_xcd <= 2 * g_cus_per_xcd) ? g_cus_per_xcd : 0;
     // in-kernel (last-arriver) reduction up to GDPSO_SPLITK_FUSED_MAX splits (default: off); one counter per workgroup index
     *fused_reduce = L.splits > 1 && L.splits <= g_fused_max_splits && (size_t)*grid_x * sizeof(int) <= SPLITK_COUNTER_BYTES;
     a.part = L.splits > 1 ? splitk_ws + SPLITK_COUNTER_BYTES / sizeof(float) : nullptr;

@@ -57,6 +57,22 @@ def main():
         print(f"  {name:36s} median {np.median(v):6.2f} us   p90 {np.percentile(v, 90):6.2f}   max {v.max():6.2f}")
     life = (s[:, 3] - s[:, 0]) / (ghz * 1e3)
     print(f"  workgroup lifetime                   median {np.median(life):6.2f} us   max {life.max():6.2f}")
+    # placement: HW_REG_HW_ID (cu_id bits 11:8, sh_id 12, se_id 15:13) and HW_REG_XCC_ID per workgroup
+    full = buf.cpu().numpy().astype(np.int64)
+    ids = np.nonzero(full[:, 0] != 0)[0]
+    hw = full[ids, 5] & 0xffffffff
+    xcc = (full[ids, 5] >> 32) & 0xf
+    cu = ((hw >> 8) & 0xf) | (((hw >> 12) & 1) << 4) | (((hw >> 13) & 7) << 5)
+    print("  XCC of workgroups 0..15:", xcc[:16].tolist())
+    for x in sorted(set(xcc.tolist()))[:1]:
+        sel = ids[xcc == x]
+        cus = cu[xcc == x]
+        print(f"  XCC {x}: {len(sel)} workgroups on {len(set(cus.tolist()))} CUs; workgroup ids -> CU (first 48):")
+        print("   ", [(int(i), int(c)) for i, c in list(zip(sel, cus))[:48]])
+        per = {}
+        for i, c in zip(sel, cus):
+            per.setdefault(int(c), []).append(int(i) >> 3)
+        print("    slots per CU:", sorted(per.items())[:12])
     second = start > np.median(life) * 0.5
     print(f"  workgroups that started after half a median lifetime (a later round): {int(second.sum())}")
 
