@@ -66,16 +66,17 @@ def test_assessor_shapes(eng, synth, model, side):
 
 
 def test_batch_tail_and_large_batch(eng, nets, oracle, synth):
-    """Batch sizes that are not a multiple of any tile (M tail rows) and a 512 batch agree
-    with the oracle on the same seeded latents."""
+    """Batch sizes that are not a multiple of any tile (M tail rows, partly filled phases, every
+    tile shape and launch form the planner picks along the way) and a 512 batch agree with the
+    oracle on the same seeded latents."""
     ev = nets[10]
     gsd = synth.to_torch(synth.generator_state(10, 1, 64, seed=11))
     csd = synth.to_torch(synth.resnet_state("ResNet50", 1, 8, seed=12))
     fit = oracle.Fitness(gsd, csd, 6)
     spec = eng.FitnessSpec(class_index=6)
     rs = np.random.RandomState(3)
-    for n in (1, 3, 37, 512):
+    for n in (1, 3, 37, 100, 257, 300, 512, 1000):
         z = rs.standard_normal((n, 10))
         got, _, _ = ev.fitness(torch.from_numpy(z).cuda(), spec)
-        sel = np.arange(n) if n <= 37 else rs.choice(n, 24, replace=False)
+        sel = np.arange(n) if n <= 37 else np.concatenate([[0, n - 1], rs.choice(n, 14, replace=False)])
         np.testing.assert_allclose(got.cpu().numpy()[sel], fit(z[sel]), atol=TOL)
