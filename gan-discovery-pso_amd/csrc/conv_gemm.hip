@@ -991,3 +991,48 @@ extern "C" int gdpso_conv_probe(int n_images, int hin, int cin, int cout, int ks
     if (splits_used) *splits_used = L.splits;
     return GDPSO_OK;
 }
+
+// Runs ONE convolution layer on the caller's data (test aid: lets a test drive every tile
+// shape and split count on arbitrary layer shapes, which whole-network tests reach only by
+// way of the planner).  weight/scale/shift are host arrays (weight in PyTorch layout:
+// [cout][cin][k][k], or [cin][cout][4][4] when `transposed`, which means ConvTranspose2d
+// k4 s2 p1); in/res/out are device NHWC arrays.  tile = 0 / splits = 0 keep the planner's
+// choice.  Allocates and frees its own device copies; synchronises before returning.
+extern "C" int gdpso_conv_layer_run(int n_images, int hin, int cin, int cout, int ksize, int stride, int pad,
+                                    int transposed, int act, int tile, int splits, const float *weight,
+                                    const float *scale, const float *shift, const float *in, const float *res,
+                                    float *out, int *tile_used, int *splits_used) {
+    using namespace gdpso;
+    GDPSO_REQUIRE(n_images > 0 && hin > 0 && cin > 0 && cin % 32 == 0 && cout > 0 && cout % 64 == 0, "conv_layer_run: bad shape");
+    GDPSO_REQUIRE(weight && scale && shift && in && out, "conv_layer_run: null pointer");
+    GDPSO_REQUIRE(act == ACT_NONE || act == ACT_RELU || act == ACT_LEAKY02, "conv_layer_run: bad activation");
+    GDPSO_REQUIRE(transposed || (ksize > 0 && stride > 0 && pad >= 0 && hin + 2 * pad >= ksize), "conv_layer_run: bad window");
+    GDPSO_REQUIRE(tile == 0 || tile == 64 || (tile == 32 && cin % 64 == 0) || (tile == TILE_32x32 && cin % 128 == 0) ||
+                      (tile == 128 && cout % 128 == 0),
+                  "conv_layer_run: bad tile");
+    GDPSO_REQUIRE(splits >= 0 && splits <= 16, "conv_layer_run: bad split count");
+    ConvLayer L;
+    std::vector<float> packed, sc(scale, scale + cout), sh(shift, shift + cout);
+    if (transposed)
+        make_convt_k4s2p1(L, weight, cin, cout, hin, hin, (Act)act, packed);
+    else
+        make_conv(L, weight, cout, cin, ksize, ksize, stride, pad, hin, hin, (Act)act, packed);
+    DeviceArena arena;
+    int rc = upload_conv(arena, L, packed, sc, sh);
+    if (rc) return rc;
+    int dev = 0, cus = 256;
+    GDPSO_HIP(hipGetDevice(&dev));
+    GDPSO_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if ((rc = plan_conv(L, n_images, cus))) return rc;
+    if (tile) L.tile = tile;
+    if (splits) L.splits = splits;
+    float *d_sk = nullptr;
+    GDPSO_HIP(hipMalloc(&d_sk, conv_splitk_bytes(L, n_images)));
+    arena.blocks.push_back(d_sk);
+    GDPSO_HIP(hipMemset(d_sk, 0, SPLITK_COUNTER_BYTES));
+    if ((rc = launch_conv(L, nullptr, n_images, in, res, out, d_sk))) return rc;
+    GDPSO_HIP(hipStreamSynchronize(nullptr));
+    if (tile_used) *tile_used = L.tile;
+    if (splits_used) *splits_used = L.splits;
+    return GDPSO_OK;
+}

@@ -281,6 +281,18 @@ int gdpso_conv_plan_describe(int n_images, int hin, int cin, int cout, int ksize
 int gdpso_conv_probe(int n_images, int hin, int cin, int cout, int ksize, int stride, int pad, int tile,
                      int splits, int with_res, int reps, double *avg_us, int *tile_used, int *splits_used);
 
+/* No counterpart in the reference: runs ONE convolution layer on the caller's data (a test
+ * aid; whole-network calls reach a tile shape or split count only by way of the planner).
+ * weight / scale / shift are HOST arrays: weight in PyTorch layout, [cout][cin][k][k], or
+ * [cin][cout][4][4] when `transposed` (= ConvTranspose2d k4 s2 p1; ksize/stride/pad ignored);
+ * out = act(conv(in) * scale[c] + shift[c] + res), act 0 none / 1 ReLU / 2 LeakyReLU(0.2).
+ * in / res (may be null) / out are DEVICE arrays in NHWC.  tile and splits as for
+ * gdpso_conv_probe.  Allocates and frees its own device copies of the weights and the
+ * split-K workspace, runs on the null stream and synchronises before returning. */
+int gdpso_conv_layer_run(int n_images, int hin, int cin, int cout, int ksize, int stride, int pad, int transposed,
+                         int act, int tile, int splits, const float *weight, const float *scale, const float *shift,
+                         const float *in, const float *res, float *out, int *tile_used, int *splits_used);
+
 #ifdef __cplusplus
 }
 #endif

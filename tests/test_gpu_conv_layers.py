@@ -1,0 +1,132 @@
+"""One convolution layer at a time through the C ABI (gdpso_conv_layer_run), with the tile
+shape and the split count forced, against torch's float64 convolution of the same data.
+
+Whole-network tests reach a tile shape only when the planner picks it (the 128x128 tile, for
+one, needs more work than any test-sized network offers); here every instantiation of the
+kernel runs on shapes that exercise row tails, partly filled phases, border classes of padded
+windows, strides, the four sub-pixel phases of the transposed convolution, residuals and every
+activation.  Tolerance: 1e-4 absolute on outputs of unit scale (fp32 accumulation over K up
+to 4608 terms stays below 2e-5 here)."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+T128, T64, T32, T16 = 128, 64, 32, 16
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return importlib.import_module("gan-discovery-pso_amd._lib")
+
+
+def run_layer(lib, n, hin, cin, cout, k, stride, pad, transposed, act, tile, splits, with_res, seed):
+    rng = np.random.default_rng(seed)
+    taps = 16 if transposed else k * k
+    wshape = (cin, cout, 4, 4) if transposed else (cout, cin, k, k)
+    w = (rng.standard_normal(wshape) / np.sqrt(cin * taps / (4 if transposed else 1))).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.uniform(-0.5, 0.5, cout).astype(np.float32)
+    x = rng.standard_normal((n, cin, hin, hin)).astype(np.float32)
+    xt = torch.from_numpy(x).double()
+    if transposed:
+        y = F.conv_transpose2d(xt, torch.from_numpy(w).double(), stride=2, padding=1)
+    else:
+        y = F.conv2d(xt, torch.from_numpy(w).double(), stride=stride, padding=pad)
+    y = y * torch.from_numpy(scale).double()[None, :, None, None] + torch.from_numpy(shift).double()[None, :, None, None]
+    res = None
+    if with_res:
+        res = rng.standard_normal(tuple(y.shape)).astype(np.float32)
+        y = y + torch.from_numpy(res).double()
+    if act == 1:
+        y = torch.relu(y)
+    elif act == 2:
+        y = F.leaky_relu(y, 0.2)
+    want = y.permute(0, 2, 3, 1).contiguous().numpy()
+
+    d_in = torch.from_numpy(np.ascontiguousarray(x.transpose(0, 2, 3, 1))).cuda()
+    d_res = torch.from_numpy(np.ascontiguousarray(res.transpose(0, 2, 3, 1))).cuda() if with_res else None
+    d_out = torch.full(want.shape, float("nan"), dtype=torch.float32, device="cuda")
+    tile_used, splits_used = C.c_int(0), C.c_int(0)
+    torch.cuda.synchronize()
+    lib.check(lib.lib().gdpso_conv_layer_run(
+        n, hin, cin, cout, k, stride, pad, int(transposed), act, tile, splits,
+        w.ctypes.data, scale.ctypes.data, shift.ctypes.data,
+        d_in.data_ptr(), lib.ptr(d_res), d_out.data_ptr(), C.byref(tile_used), C.byref(splits_used)))
+    got = d_out.cpu().numpy()
+    assert np.isfinite(got).all(), "some output element was never written"
+    np.testing.assert_allclose(got, want, atol=TOL, rtol=0)
+    return tile_used.value, splits_used.value
+
+
+# (n, hin, cin, cout, k, stride, pad): ResNet-like layers at sizes with row tails
+SHAPES = [
+    (3, 7, 128, 128, 3, 1, 1),    # 3x3 pad 1: nine border classes, 147 rows (tail in every tile)
+    (5, 14, 256, 128, 1, 1, 0),   # 1x1
+    (2, 14, 128, 256, 1, 2, 0),   # strided 1x1 (identity_downsample)
+    (2, 14, 128, 128, 3, 2, 1),   # strided 3x3: border classes on the first row/column only
+    (1, 4, 256, 128, 3, 1, 1),    # tiny map: the middle class is 2x2
+    (1, 1, 128, 128, 3, 1, 1),    # 1x1 map with padding: a single class with one live tap
+    (7, 5, 128, 128, 3, 1, 0),    # unpadded window
+]
+
+
+@pytest.mark.parametrize("tile", [T128, T64, T32, T16])
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_every_tile_shape(lib, tile, shape):
+    n, hin, cin, cout, k, stride, pad = shape
+    t, s = run_layer(lib, n, hin, cin, cout, k, stride, pad, False, act=1, tile=tile, splits=1, with_res=True,
+                     seed=hash((tile,) + shape) & 0xffff)
+    assert (t, s) == (tile, 1)
+
+
+@pytest.mark.parametrize("tile", [T128, T64, T32, T16])
+@pytest.mark.parametrize("splits", [2, 3, 5, 16])
+def test_split_k(lib, tile, splits):
+    """K split over blockIdx.z into slabs (uneven last part; 16 leaves some parts empty at K=128)."""
+    for shape, act, res in (((2, 7, 128, 128, 3, 1, 1), 1, True), ((3, 5, 128, 256, 1, 1, 0), 0, False)):
+        t, s = run_layer(lib, *shape, False, act=act, tile=tile, splits=splits, with_res=res, seed=tile * 31 + splits)
+        assert (t, s) == (tile, splits)
+
+
+@pytest.mark.parametrize("act", [0, 1, 2])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_activations_and_residual(lib, act, with_res):
+    run_layer(lib, 4, 7, 64, 64, 3, 1, 1, False, act=act, tile=0, splits=0, with_res=with_res, seed=act * 2 + with_res)
+
+
+@pytest.mark.parametrize("tile", [0, T128, T64, T32, T16])
+def test_transposed_k4s2p1(lib, tile):
+    """ConvTranspose2d(k4, s2, p1): four sub-pixel phases, each with its own border classes."""
+    run_layer(lib, 3, 7, 128, 128, 4, 2, 1, True, act=2, tile=tile, splits=1, with_res=False, seed=77 + tile)
+    run_layer(lib, 2, 3, 128, 64 if tile in (0, T64, T32, T16) else 128, 4, 2, 1, True, act=0, tile=tile, splits=2,
+              with_res=False, seed=78 + tile)
+
+
+def test_planner_choice_on_wide_layers(lib):
+    """Layers big enough for the planner itself to pick the 128x128 tile, and deep K."""
+    t, _ = run_layer(lib, 192, 14, 256, 512, 1, 1, 0, False, act=1, tile=0, splits=0, with_res=True, seed=5)
+    assert t == T128
+    run_layer(lib, 2, 4, 512, 64, 3, 1, 1, False, act=1, tile=0, splits=0, with_res=False, seed=6)  # K = 4608
+
+
+def test_rejects_bad_arguments(lib):
+    x = torch.zeros(1, 4, 4, 32, device="cuda")
+    out = torch.zeros(1, 4, 4, 64, device="cuda")
+    w = np.zeros((64, 32, 1, 1), np.float32)
+    v = np.zeros(64, np.float32)
+    call = lib.lib().gdpso_conv_layer_run
+    # tile 32 needs cin % 64 == 0
+    assert call(1, 4, 32, 64, 1, 1, 0, 0, 0, T32, 1, w.ctypes.data, v.ctypes.data, v.ctypes.data, x.data_ptr(), 0,
+                out.data_ptr(), None, None) != 0
+    # cout must be a multiple of 64
+    assert call(1, 4, 32, 48, 1, 1, 0, 0, 0, 0, 0, w.ctypes.data, v.ctypes.data, v.ctypes.data, x.data_ptr(), 0,
+                out.data_ptr(), None, None) != 0
+    # null input
+    assert call(1, 4, 32, 64, 1, 1, 0, 0, 0, 0, 0, w.ctypes.data, v.ctypes.data, v.ctypes.data, 0, 0,
+                out.data_ptr(), None, None) != 0
