@@ -80,3 +80,17 @@ def test_batch_tail_and_large_batch(eng, nets, oracle, synth):
         got, _, _ = ev.fitness(torch.from_numpy(z).cuda(), spec)
         sel = np.arange(n) if n <= 37 else np.concatenate([[0, n - 1], rs.choice(n, 14, replace=False)])
         np.testing.assert_allclose(got.cpu().numpy()[sel], fit(z[sel]), atol=TOL)
+
+
+@pytest.mark.parametrize("model", ["ResNet101", "ResNet152"])
+def test_deep_assessors_against_oracle(eng, oracle, synth, model):
+    """The 101- and 152-layer assessors (reference util_cnn.py:105-116) on generated images, an
+    odd batch size, against the oracle's restatement of the same weights."""
+    dev = torch.device("cuda:0")
+    gstate = synth.generator_state(10, 1, 64, seed=21)
+    cstate = synth.resnet_state(model, 1, 8, seed=22)
+    ev = eng.Evaluator(eng.PackedGenerator(gstate, dev), eng.PackedAssessor(cstate, dev, img_side=28))
+    fit = oracle.Fitness(synth.to_torch(gstate), synth.to_torch(cstate), 2)
+    z = np.random.RandomState(8).standard_normal((11, 10))
+    got, _, _ = ev.fitness(torch.from_numpy(z).cuda(), eng.FitnessSpec(class_index=2))
+    np.testing.assert_allclose(got.cpu().numpy(), fit(z), atol=TOL)
