@@ -321,15 +321,20 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
     // Prefetch registers for the next K-tile.  Native vector types over fully unrolled loops:
     // with HIP's float4 struct these arrays were not promoted to registers (they went to
     // scratch, which put a wait behind every prefetch).
-    f32x4 ra[PA], rb[PB];
-#define GDPSO_GLOAD()                                                                                           \
+    // Tiles of one MFMA block per wave spend too little time in a K-step (16 MFMAs, ~0.5 us) to
+    // cover a load's latency: they keep TWO K-tiles in flight, in two register sets that are
+    // always named by literal index (a run-time index would put the arrays in scratch).
+    constexpr bool PF2 = WM * WN == 1;
+    constexpr int NSET = PF2 ? 2 : 1;
+    f32x4 ra[NSET][PA], rb[NSET][PB];
+#define GDPSO_GLOAD(S)                                                                                          \
     {                                                                                                           \
         _Pragma("unroll") for (int p = 0; p < PA; ++p) {                                                        \
-            ra[p] = *(global_f32x4_ptr)aptr[p];                                                                  \
+            ra[S][p] = *(global_f32x4_ptr)aptr[p];                                                               \
             aptr[p] += BKT;                                                                                     \
         }                                                                                                       \
         _Pragma("unroll") for (int p = 0; p < PB; ++p) {                                                        \
-            rb[p] = *(global_f32x4_ptr)bptr[p];                                                                  \
+            rb[S][p] = *(global_f32x4_ptr)bptr[p];                                                               \
             bptr[p] += BKT;                                                                                     \
         }                                                                                                       \
         ci0 += BKT;                                                                                             \
@@ -338,12 +343,12 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
             if (++tap < ntaps) GDPSO_SET_TAP(0)                                                                 \
         }                                                                                                       \
     }
-#define GDPSO_SSTORE(BUF)                                                                                       \
+#define GDPSO_SSTORE(BUF, S)                                                                                    \
     {                                                                                                           \
         _Pragma("unroll") for (int p = 0; p < PA; ++p)                                                          \
-            *(f32x4 *)&sA[(BUF) * BM * LDA + (lrow + RP * p) * LDA + lcol] = ra[p];                             \
+            *(f32x4 *)&sA[(BUF) * BM * LDA + (lrow + RP * p) * LDA + lcol] = ra[S][p];                          \
         _Pragma("unroll") for (int p = 0; p < PB; ++p)                                                          \
-            *(f32x4 *)&sB[(BUF) * BN * LDA + (lrow + RP * p) * LDA + lcol] = rb[p];                             \
+            *(f32x4 *)&sB[(BUF) * BN * LDA + (lrow + RP * p) * LDA + lcol] = rb[S][p];                          \
     }
     // Operand fragments of MFMA group G (8 k's) into register set SET.
 #define GDPSO_LOADFRAG(SET, G)                                                                                  \
@@ -360,10 +365,14 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (kbeg < kend) {
+    const int nk = kbeg < kend ? (kend - kbeg) / BKT : 0;  // K-tiles of this workgroup
+    if (nk > 0) {
         GDPSO_SET_TAP(ci0)
-        GDPSO_GLOAD()
-        GDPSO_SSTORE(0)
+        GDPSO_GLOAD(0)
+        if constexpr (PF2) {
+            if (nk > 1) GDPSO_GLOAD(1)
+        }
+        GDPSO_SSTORE(0, 0)
     }
     __syncthreads();
     GDPSO_STAMP(1)
@@ -374,16 +383,16 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
     // registers to the other LDS buffer ahead of the last group, in the shadow of the MFMAs that
     // are still executing, instead of after them.  The sched_group_barrier sequence pins that
     // order (0x100 = DS read, 0x200 = DS write, 0x008 = MFMA).
-#define GDPSO_KSTEP(MORE)                                                                                       \
+#define GDPSO_KSTEP(LOAD, LS, MORE, SS)                                                                         \
     {                                                                                                           \
-        if (MORE) GDPSO_GLOAD()                                                                                 \
+        if (LOAD) GDPSO_GLOAD(LS)                                                                               \
         const float *pa = sA + buf * BM * LDA + (wr * (BM / 2) + l31) * LDA + half * 4 + kh * 32;               \
         const float *pb = sB + buf * BN * LDA + (wc * (BN / 2) + l31) * LDA + half * 4 + kh * 32;               \
         f32x4 av[2][WM], bv[2][WN];                                                                             \
         GDPSO_LOADFRAG(0, 0)                                                                                    \
         _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                         \
             if (g < 3) GDPSO_LOADFRAG((g + 1) & 1, g + 1)                                                       \
-            if (g == 3 && (MORE)) GDPSO_SSTORE(buf ^ 1)                                                         \
+            if (g == 3 && (MORE)) GDPSO_SSTORE(buf ^ 1, SS)                                                     \
             _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                       \
                 _Pragma("unroll") for (int i = 0; i < WM; ++i)                                                  \
                     _Pragma("unroll") for (int j = 0; j < WN; ++j)                                              \
@@ -400,8 +409,29 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
         buf ^= 1;                                                                                               \
     }
     int buf = 0;
-    for (int kt = kbeg; kt + BKT < kend; kt += BKT) GDPSO_KSTEP(true)
-    if (kbeg < kend) GDPSO_KSTEP(false)
+    if constexpr (PF2) {
+        // K-tile t travels through register set t & 1: step t issues the loads of tile t + 2 into
+        // the set that tile t left, and moves tile t + 1 (loaded a whole step ago) into LDS.
+        int t = 0;
+        for (; t + 3 < nk; t += 2) {
+            GDPSO_KSTEP(true, 0, true, 1)
+            GDPSO_KSTEP(true, 1, true, 0)
+        }
+        const int left = nk - t;  // 0 (empty K range), 1, 2 or 3; t is even
+        if (left == 3) {
+            GDPSO_KSTEP(true, 0, true, 1)
+            GDPSO_KSTEP(false, 0, true, 0)
+            GDPSO_KSTEP(false, 0, false, 0)
+        } else if (left == 2) {
+            GDPSO_KSTEP(false, 0, true, 1)
+            GDPSO_KSTEP(false, 0, false, 0)
+        } else if (left == 1) {
+            GDPSO_KSTEP(false, 0, false, 0)
+        }
+    } else {
+        for (int t = 0; t + 1 < nk; ++t) GDPSO_KSTEP(true, 0, true, 0)
+        if (nk > 0) GDPSO_KSTEP(false, 0, false, 0)
+    }
 #undef GDPSO_KSTEP
 #undef GDPSO_SET_TAP
 #undef GDPSO_GLOAD
