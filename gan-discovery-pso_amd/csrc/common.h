@@ -115,4 +115,20 @@ void make_convt_k4s2p1(ConvLayer &L, const float *w, int cin, int cout, int hin,
 
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Division by a run-time constant d >= 1 without a divide: for 0 <= n < 2^31,
+// n / d == (uint64(n) * mul) >> shift with shift = 31 + ceil(log2 d), mul = ceil(2^shift / d)
+// (mul * d - 2^shift < d <= 2^(shift - 31), so the error term n * that / 2^shift stays below 1 / d).
+// The GPU has no integer divide: the compiler's expansion is some thirty dependent instructions.
+struct FastDiv {
+    unsigned mul, shift;
+};
+inline FastDiv fast_div_for(unsigned d) {
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    FastDiv f;
+    f.shift = 31 + s;
+    f.mul = (unsigned)(((1ull << f.shift) + d - 1) / d);
+    return f;
+}
+
 }  // namespace gdpso

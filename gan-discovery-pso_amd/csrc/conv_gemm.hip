@@ -67,6 +67,7 @@ struct ConvKArgs {
     long slab;  // elements per split-K slab
     int phase_tiles[MAX_PHASES];  // tiles (M-tiles x column tiles) of each phase
     int phase_end[MAX_PHASES];    // running sum over phases of ceil(phase_tiles / 8) (INT_MAX past the last)
+    unsigned tiles_n_mul, tiles_n_shift;  // FastDiv by tiles_n
     int per_xcd;                  // workgroups of this layer per XCD (= the last phase_end)
     int snake;                    // CUs per XCD when the second round of workgroups is dealt in reverse, else 0
 };
@@ -86,7 +87,13 @@ struct FuseArgs {
 struct PhaseInfo {
     int M, hm, wm;      // rows of this phase = n_images * hm * wm
     int off_y, off_x;   // output pixel = (my * out_mul + off_y, mx * out_mul + off_x)
+    unsigned hw_mul, hw_shift, wm_mul, wm_shift;  // FastDiv by hm * wm and by wm
 };
+
+// n / d for 0 <= n < 2^31 (see FastDiv)
+__device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned shift) {
+    return (int)(((unsigned long long)(unsigned)n * mul) >> shift);
+}
 
 // Taps that fall into the padding (and tail rows past M) read from here instead of
 // branching around the load: a conditional load would make the compiler wait for the whole
@@ -142,8 +149,8 @@ __device__ __forceinline__ void conv_store_tile(const ConvKArgs &a, float *lds, 
         const int m = m0 + pass * RPP + r0;
         size_t pix = (size_t)m;
         if (remap && m < P.M) {
-            const int n = m / hw, rr = m - n * hw;
-            const int my = rr / P.wm, mx = rr - my * P.wm;
+            const int n = fast_div(m, P.hw_mul, P.hw_shift), rr = m - n * hw;
+            const int my = fast_div(rr, P.wm_mul, P.wm_shift), mx = rr - my * P.wm;
             pix = ((size_t)n * a.hout + my * a.out_mul + P.off_y) * a.wout + mx * a.out_mul + P.off_x;
         }
         off[pass] = m < P.M ? (long)(pix * a.cout + col) : -1;
@@ -261,7 +268,7 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
     const int idx = xcd * per_xcd + (slot - base);
     if (idx >= a.phase_tiles[ph]) return;
     const int tile = bx;
-    const int tml = idx / a.tiles_n, tn = idx - tml * a.tiles_n;
+    const int tml = fast_div(idx, a.tiles_n_mul, a.tiles_n_shift), tn = idx - tml * a.tiles_n;
     const int m0 = tml * BM, n0 = tn * BN;
     const int sp = blockIdx.z;
     const int *tab = a.table + ph * PHASE_TABLE_INTS;
@@ -272,10 +279,15 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
     P.hm = tab[4];
     P.wm = tab[5];
     P.M = a.n_images * P.hm * P.wm;
+    P.hw_mul = (unsigned)tab[9];
+    P.wm_mul = (unsigned)tab[10];
+    P.hw_shift = (unsigned)tab[11] & 0xff;
+    P.wm_shift = ((unsigned)tab[11] >> 8) & 0xff;
     const int in_y0 = tab[6], in_x0 = tab[7], wstride = tab[8];
     const float *wt = a.wt + tab[3];
     const int ktot = ntaps * a.cin;
-    const int ksplit = ((ktot / BKT + a.splits - 1) / a.splits) * BKT;  // this phase's K range per split
+    // this phase's K range per split (the divide only where K is split at all)
+    const int ksplit = a.splits == 1 ? ktot : ((ktot / BKT + a.splits - 1) / a.splits) * BKT;
     const int kbeg = sp * ksplit;
     const int kend = min(ktot, kbeg + ksplit);
 
@@ -289,8 +301,8 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
         const int m = m0 + lrow + RP * p;
         a_ok[p] = m < P.M;
         const int mm = a_ok[p] ? m : 0;
-        const int n = mm / hw, r = mm - n * hw;
-        const int my = r / P.wm, mx = r - my * P.wm;
+        const int n = fast_div(mm, P.hw_mul, P.hw_shift), r = mm - n * hw;
+        const int my = fast_div(r, P.wm_mul, P.wm_shift), mx = r - my * P.wm;
         a_iy0[p] = my * a.in_stride + in_y0;
         a_ix0[p] = mx * a.in_stride + in_x0;
         a_img[p] = n * a.hin * a.win;
@@ -304,7 +316,7 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
     const float *brow[PB];
 #pragma unroll
     for (int p = 0; p < PB; ++p) brow[p] = wt + (size_t)(n0 + lrow + RP * p) * wstride + lcol;
-    int tap = kbeg / a.cin, ci0 = kbeg - tap * a.cin;
+    int tap = a.splits == 1 ? 0 : kbeg / a.cin, ci0 = kbeg - tap * a.cin;
 #define GDPSO_SET_TAP(CI)                                                                                       \
     {                                                                                                           \
         const int packed_ = tab[PHASE_HDR + tap];                                                               \
@@ -462,8 +474,8 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
             const int m = m0 + pass * 16 + r0;
             size_t pix = (size_t)m;
             if (remap && m < P.M) {
-                const int n = m / hw2, rr = m - n * hw2;
-                const int my = rr / P.wm, mx = rr - my * P.wm;
+                const int n = fast_div(m, P.hw_mul, P.hw_shift), rr = m - n * hw2;
+                const int my = fast_div(rr, P.wm_mul, P.wm_shift), mx = rr - my * P.wm;
                 pix = ((size_t)n * a.hout + my * a.out_mul + P.off_y) * a.wout + mx * a.out_mul + P.off_x;
             }
             off[pass] = m < P.M ? (long)(pix * f.cout + c4 * 4) : -1;
@@ -742,6 +754,9 @@ static int conv_args(const ConvLayer &L, int n_images, const float *in, const fl
     a.in_stride = L.in_stride; a.out_mul = L.out_mul;
     a.act = L.act; a.splits = L.splits;
     a.tiles_n = L.cout / tile_bn(L.tile);
+    const FastDiv dn = fast_div_for((unsigned)a.tiles_n);
+    a.tiles_n_mul = dn.mul;
+    a.tiles_n_shift = dn.shift;
     a.slab = (long)n_images * L.hout * L.wout * L.cout;
     if (L.cin % BK != 0 || L.cin > MAX_CIN) return fail(GDPSO_ERR_ARG, "conv: cin must be a multiple of 32, at most 4096");
     if (L.splits > 1 && !splitk_ws) return fail(GDPSO_ERR_WORKSPACE, "conv: split-K workspace missing");

@@ -234,7 +234,7 @@ void make_convt_k4s2p1(ConvLayer &L, const float *w, int cin, int cout, int hin,
 }
 
 // Device table of a layer: per phase PHASE_HDR ints {ntaps, off_y, off_x, wt_offset, hm, wm,
-// in_y0, in_x0, wstride, 0, 0, 0} followed by MAX_TAPS packed taps (dy & 0xff) | (dx & 0xff) << 8
+// in_y0, in_x0, wstride, mul(hm * wm), mul(wm), shift(hm * wm) | shift(wm) << 8} (mul / shift: FastDiv) followed by MAX_TAPS packed taps (dy & 0xff) | (dx & 0xff) << 8
 // | wtap << 16.
 int upload_conv(DeviceArena &arena, ConvLayer &L, const std::vector<float> &packed,
                 const std::vector<float> &scale, const std::vector<float> &shift) {
@@ -251,6 +251,10 @@ int upload_conv(DeviceArena &arena, ConvLayer &L, const std::vector<float> &pack
         t[6] = P.in_y0;
         t[7] = P.in_x0;
         t[8] = P.wstride;
+        const FastDiv dhw = fast_div_for((unsigned)(P.hm * P.wm)), dw = fast_div_for((unsigned)P.wm);
+        t[9] = (int)dhw.mul;
+        t[10] = (int)dw.mul;
+        t[11] = (int)(dhw.shift | (dw.shift << 8));
         for (int k = 0; k < P.ntaps; ++k)
             t[PHASE_HDR + k] = ((int)P.dy[k] & 0xff) | (((int)P.dx[k] & 0xff) << 8) | ((int)P.wtap[k] << 16);
     }
