@@ -142,18 +142,19 @@ __device__ __forceinline__ void conv_store_tile(const ConvKArgs &a, float *lds, 
     const bool direct = a.splits == 1;
     const f32x4 sc = *(const f32x4 *)(a.scale + col), sh = *(const f32x4 *)(a.shift + col);
     const bool remap = a.out_mul != 1 || P.hm != a.hout || P.wm != a.wout;
-    // element offset of this thread's 4 channels in each of its rows (-1: row past M)
-    long off[PASSES];
+    // element offset of this thread's 4 channels in each of its rows (-1: row past M); 32 bits
+    // are enough, the host refuses outputs of 2 GiB and more
+    int off[PASSES];
 #pragma unroll
     for (int pass = 0; pass < PASSES; ++pass) {
         const int m = m0 + pass * RPP + r0;
-        size_t pix = (size_t)m;
+        int pix = m;
         if (remap && m < P.M) {
             const int n = fast_div(m, P.hw_mul, P.hw_shift), rr = m - n * hw;
             const int my = fast_div(rr, P.wm_mul, P.wm_shift), mx = rr - my * P.wm;
-            pix = ((size_t)n * a.hout + my * a.out_mul + P.off_y) * a.wout + mx * a.out_mul + P.off_x;
+            pix = (n * a.hout + my * a.out_mul + P.off_y) * a.wout + mx * a.out_mul + P.off_x;
         }
-        off[pass] = m < P.M ? (long)(pix * a.cout + col) : -1;
+        off[pass] = m < P.M ? pix * a.cout + col : -1;
     }
     if (direct) {
 #pragma unroll
@@ -189,7 +190,7 @@ __device__ __forceinline__ void conv_store_tile(const ConvKArgs &a, float *lds, 
             if (off[pass] >= 0)
                 __builtin_amdgcn_raw_buffer_store_b128(
                     __builtin_bit_cast(u32x4, *(const f32x4 *)&sC[(pass * RPP + r0) * LDC + c4 * 4]), rsrc,
-                    (int)(off[pass] * 4), 0, 16 /* sc1 */);
+                    off[pass] * 4, 0, 16 /* sc1 */);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -315,7 +316,7 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
     const float *aptr[PA], *bptr[PB];
     const float *brow[PB];
 #pragma unroll
-    for (int p = 0; p < PB; ++p) brow[p] = wt + (size_t)(n0 + lrow + RP * p) * wstride + lcol;
+    for (int p = 0; p < PB; ++p) brow[p] = wt + ((n0 + lrow + RP * p) * wstride + lcol);  // 32-bit offsets: see conv_args
     int tap = a.splits == 1 ? 0 : kbeg / a.cin, ci0 = kbeg - tap * a.cin;
 #define GDPSO_SET_TAP(CI)                                                                                       \
     {                                                                                                           \
@@ -325,7 +326,7 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
         _Pragma("unroll") for (int p = 0; p < PA; ++p) {                                                        \
             const int iy = a_iy0[p] + dy_, ix = a_ix0[p] + dx_;                                                 \
             const bool ok = a_ok[p] && (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;        \
-            aptr[p] = ok ? a.in + (size_t)(a_img[p] + iy * a.win + ix) * a.cin + (CI) + lcol                    \
+            aptr[p] = ok ? a.in + ((a_img[p] + iy * a.win + ix) * a.cin + (CI) + lcol)                          \
                          : g_zero_page + (CI) + lcol;                                                           \
         }                                                                                                       \
         _Pragma("unroll") for (int p = 0; p < PB; ++p) bptr[p] = brow[p] + wk_;                                 \
@@ -468,17 +469,17 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
         const int c4 = tid & 15, r0 = tid >> 4;  // 16 threads x 16 B per 64-float row, 16 rows per pass
         const int hw2 = P.hm * P.wm;
         const bool remap = a.out_mul != 1 || P.hm != a.hout || P.wm != a.wout;
-        long off[4];
+        int off[4];
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
             const int m = m0 + pass * 16 + r0;
-            size_t pix = (size_t)m;
+            int pix = m;
             if (remap && m < P.M) {
                 const int n = fast_div(m, P.hw_mul, P.hw_shift), rr = m - n * hw2;
                 const int my = fast_div(rr, P.wm_mul, P.wm_shift), mx = rr - my * P.wm;
-                pix = ((size_t)n * a.hout + my * a.out_mul + P.off_y) * a.wout + mx * a.out_mul + P.off_x;
+                pix = (n * a.hout + my * a.out_mul + P.off_y) * a.wout + mx * a.out_mul + P.off_x;
             }
-            off[pass] = m < P.M ? (long)(pix * f.cout + c4 * 4) : -1;
+            off[pass] = m < P.M ? pix * f.cout + c4 * 4 : -1;
         }
         const int nblocks = f.cout / 64;
         f32x4 rw[4];
@@ -761,6 +762,9 @@ static int conv_args(const ConvLayer &L, int n_images, const float *in, const fl
     if (L.cin % BK != 0 || L.cin > MAX_CIN) return fail(GDPSO_ERR_ARG, "conv: cin must be a multiple of 32, at most 4096");
     if (L.splits > 1 && !splitk_ws) return fail(GDPSO_ERR_WORKSPACE, "conv: split-K workspace missing");
     if (a.slab * 4 >= (1L << 31)) return fail(GDPSO_ERR_ARG, "conv: output larger than 2 GiB");
+    // the kernel forms element offsets into the input and the weights in 32 bits
+    if ((long)n_images * L.hin * L.win * L.cin * 4 >= (1L << 31)) return fail(GDPSO_ERR_ARG, "conv: input larger than 2 GiB");
+    if ((long)L.weight_floats * 4 >= (1L << 31)) return fail(GDPSO_ERR_ARG, "conv: weights larger than 2 GiB");
     if (tiles_total >= (1L << 30) || (long)n_images * L.hout * L.wout >= (1L << 31)) return fail(GDPSO_ERR_ARG, "conv: too many rows");
     if (L.tile == 32 && L.cin % 64 != 0) return fail(GDPSO_ERR_ARG, "conv: the 32-row tile needs cin to be a multiple of 64");
     if (L.tile == TILE_32x32 && L.cin % 128 != 0) return fail(GDPSO_ERR_ARG, "conv: the 32x32 tile needs cin to be a multiple of 128");
