@@ -128,12 +128,20 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // The tile has been laid out row-major in LDS ([BM][BN + 4], starting at `lds`) and a barrier
 // has passed; it is written with 16-byte stores: one wave instruction covers whole 256/512-byte
 // row segments, and the residual is read the same way.
-template <int BM, int BN>
+// KP > 1: the tile arrives as KP partial tiles (regions of BM x (BN + 4) floats, one per K part
+// of the workgroup), which are added in the order 0, 1, ... as they are read.
+template <int BM, int BN, int KP = 1>
 __device__ __forceinline__ void conv_store_tile(const ConvKArgs &a, float *lds, int lds_floats, int tid, int m0, int n0,
                                                 int sp, int tile, const PhaseInfo &P) {
     const int hw = P.hm * P.wm;
     constexpr int LDC = BN + 4;
     float *sC = lds;
+    auto tile_quad = [&](int row) {
+        f32x4 v = *(const f32x4 *)&sC[row * LDC + (tid % (BN / 4)) * 4];
+#pragma unroll
+        for (int q = 1; q < KP; ++q) v += *(const f32x4 *)&sC[q * BM * LDC + row * LDC + (tid % (BN / 4)) * 4];
+        return v;
+    };
     constexpr int C4 = BN / 4;     // float4 per tile row
     constexpr int RPP = 256 / C4;  // tile rows per pass
     constexpr int PASSES = BM / RPP;
@@ -160,7 +168,7 @@ __device__ __forceinline__ void conv_store_tile(const ConvKArgs &a, float *lds, 
 #pragma unroll
         for (int pass = 0; pass < PASSES; ++pass) {
             if (off[pass] < 0) continue;
-            f32x4 v = *(const f32x4 *)&sC[(pass * RPP + r0) * LDC + c4 * 4];
+            f32x4 v = tile_quad(pass * RPP + r0);
             v = v * sc + sh;
             if (a.res) v += *(const f32x4 *)(a.res + off[pass]);
 #pragma unroll
@@ -180,7 +188,7 @@ __device__ __forceinline__ void conv_store_tile(const ConvKArgs &a, float *lds, 
     if (a.counters == nullptr) {  // reduction by the separate kernel
 #pragma unroll
         for (int pass = 0; pass < PASSES; ++pass)
-            if (off[pass] >= 0) *(f32x4 *)(slab + off[pass]) = *(const f32x4 *)&sC[(pass * RPP + r0) * LDC + c4 * 4];
+            if (off[pass] >= 0) *(f32x4 *)(slab + off[pass]) = tile_quad(pass * RPP + r0);
         return;
     }
     {
@@ -189,7 +197,7 @@ __device__ __forceinline__ void conv_store_tile(const ConvKArgs &a, float *lds, 
         for (int pass = 0; pass < PASSES; ++pass)
             if (off[pass] >= 0)
                 __builtin_amdgcn_raw_buffer_store_b128(
-                    __builtin_bit_cast(u32x4, *(const f32x4 *)&sC[(pass * RPP + r0) * LDC + c4 * 4]), rsrc,
+                    __builtin_bit_cast(u32x4, tile_quad(pass * RPP + r0)), rsrc,
                     off[pass] * 4, 0, 16 /* sc1 */);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -540,29 +548,16 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
                 for (int r = 0; r < 16; ++r)
                     sC[(wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDC + wc * (BN / 2) + j * 32 + l31] = acc[i][j][r];
     } else {
-        // K-split layouts: the waves of K part q > 0 park their 32x32 block in region q - 1, the wave
-        // of part 0 adds them in the order q = 1, 2, ... and lays out the tile (regions of BM x LDC floats)
+        // K-split layouts: the wave of K part q leaves its 32x32 block in region q (BM x LDC floats
+        // each); the store pass adds the regions as it reads them
         constexpr int REGION = BM * LDC;
         static_assert(LDS_FLOATS >= KW * REGION + 4, "room for the partial tiles");
-        if (kh > 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                sC[kh * REGION + ((r & 3) + 8 * (r >> 2) + 4 * half) * LDC + wc * 32 + l31] = acc[0][0][r];
-        }
-        __syncthreads();
-        if (kh == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int e = ((r & 3) + 8 * (r >> 2) + 4 * half) * LDC + wc * 32 + l31;
-                float v = acc[0][0][r];
-#pragma unroll
-                for (int q = 1; q < KW; ++q) v += sC[q * REGION + e];
-                sC[e] = v;
-            }
-        }
+        for (int r = 0; r < 16; ++r)
+            sC[kh * REGION + ((r & 3) + 8 * (r >> 2) + 4 * half) * LDC + wc * 32 + l31] = acc[0][0][r];
     }
     __syncthreads();
-    conv_store_tile<BM, BN>(a, lds, LDS_FLOATS, tid, m0, n0, sp, tile, P);
+    conv_store_tile<BM, BN, KW>(a, lds, LDS_FLOATS, tid, m0, n0, sp, tile, P);
 #ifdef GDPSO_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have left the CU
     GDPSO_STAMP(3)
