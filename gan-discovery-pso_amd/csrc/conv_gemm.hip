@@ -123,6 +123,53 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
+// What a thread needs for its part of the store pass, gathered BEFORE the accumulators go to
+// LDS: the loads of scale, shift and (unsplit layers) the residual are then in flight across the
+// LDS round trip and its barrier instead of starting behind them.
+template <int BM, int BN>
+struct StorePlan {
+    static constexpr int C4 = BN / 4;     // float4 per tile row
+    static constexpr int RPP = 256 / C4;  // tile rows per pass
+    static constexpr int PASSES = BM / RPP;
+    static constexpr bool PREFETCH_RES = PASSES <= 8;  // 4 registers a pass
+    int off[PASSES];  // element offset of this thread's 4 channels in each of its rows (-1: row past M)
+    f32x4 sc, sh;
+    f32x4 rres[PREFETCH_RES ? PASSES : 1];
+};
+
+template <int BM, int BN>
+__device__ __forceinline__ void conv_store_plan(const ConvKArgs &a, int tid, int m0, int n0, const PhaseInfo &P,
+                                                StorePlan<BM, BN> &sp) {
+    using Plan = StorePlan<BM, BN>;
+    const int hw = P.hm * P.wm;
+    const int c4 = tid % Plan::C4, r0 = tid / Plan::C4;
+    const int col = n0 + c4 * 4;
+    sp.sc = *(global_f32x4_ptr)(a.scale + col);
+    sp.sh = *(global_f32x4_ptr)(a.shift + col);
+    const bool remap = a.out_mul != 1 || P.hm != a.hout || P.wm != a.wout;
+    // 32-bit offsets are enough, the host refuses outputs of 2 GiB and more
+#pragma unroll
+    for (int pass = 0; pass < Plan::PASSES; ++pass) {
+        const int m = m0 + pass * Plan::RPP + r0;
+        int pix = m;
+        if (remap && m < P.M) {
+            const int n = fast_div(m, P.hw_mul, P.hw_shift), rr = m - n * hw;
+            const int my = fast_div(rr, P.wm_mul, P.wm_shift), mx = rr - my * P.wm;
+            pix = (n * a.hout + my * a.out_mul + P.off_y) * a.wout + mx * a.out_mul + P.off_x;
+        }
+        sp.off[pass] = m < P.M ? pix * a.cout + col : -1;
+    }
+    if constexpr (Plan::PREFETCH_RES) {
+        // rows past M read the first row's residual (any valid address; the value is not used)
+        const bool want = a.splits == 1 && a.res != nullptr;
+#pragma unroll
+        for (int pass = 0; pass < Plan::PASSES; ++pass) {
+            sp.rres[pass] = 0.f;
+            if (want) sp.rres[pass] = *(global_f32x4_ptr)(a.res + (sp.off[pass] < 0 ? col : sp.off[pass]));
+        }
+    }
+}
+
 // Epilogue shared by the convolution kernels.  `lds` is the workgroup's whole LDS array
 // (lds_floats long); every operand read from it must have been retired by a barrier.
 // The tile has been laid out row-major in LDS ([BM][BN + 4], starting at `lds`) and a barrier
@@ -131,9 +178,9 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // KP > 1: the tile arrives as KP partial tiles (regions of BM x (BN + 4) floats, one per K part
 // of the workgroup), which are added in the order 0, 1, ... as they are read.
 template <int BM, int BN, int KP = 1>
-__device__ __forceinline__ void conv_store_tile(const ConvKArgs &a, float *lds, int lds_floats, int tid, int m0, int n0,
-                                                int sp, int tile, const PhaseInfo &P) {
-    const int hw = P.hm * P.wm;
+__device__ __forceinline__ void conv_store_tile(const ConvKArgs &a, float *lds, int lds_floats, int tid, int sp, int tile,
+                                                const StorePlan<BM, BN> &plan) {
+    using Plan = StorePlan<BM, BN>;
     constexpr int LDC = BN + 4;
     float *sC = lds;
     auto tile_quad = [&](int row) {
@@ -142,35 +189,22 @@ __device__ __forceinline__ void conv_store_tile(const ConvKArgs &a, float *lds, 
         for (int q = 1; q < KP; ++q) v += *(const f32x4 *)&sC[q * BM * LDC + row * LDC + (tid % (BN / 4)) * 4];
         return v;
     };
-    constexpr int C4 = BN / 4;     // float4 per tile row
-    constexpr int RPP = 256 / C4;  // tile rows per pass
-    constexpr int PASSES = BM / RPP;
-    const int c4 = tid % C4, r0 = tid / C4;
-    const int col = n0 + c4 * 4;
+    constexpr int RPP = Plan::RPP, PASSES = Plan::PASSES;
+    const int r0 = tid / Plan::C4;
     const bool direct = a.splits == 1;
-    const f32x4 sc = *(const f32x4 *)(a.scale + col), sh = *(const f32x4 *)(a.shift + col);
-    const bool remap = a.out_mul != 1 || P.hm != a.hout || P.wm != a.wout;
-    // element offset of this thread's 4 channels in each of its rows (-1: row past M); 32 bits
-    // are enough, the host refuses outputs of 2 GiB and more
-    int off[PASSES];
-#pragma unroll
-    for (int pass = 0; pass < PASSES; ++pass) {
-        const int m = m0 + pass * RPP + r0;
-        int pix = m;
-        if (remap && m < P.M) {
-            const int n = fast_div(m, P.hw_mul, P.hw_shift), rr = m - n * hw;
-            const int my = fast_div(rr, P.wm_mul, P.wm_shift), mx = rr - my * P.wm;
-            pix = (n * a.hout + my * a.out_mul + P.off_y) * a.wout + mx * a.out_mul + P.off_x;
-        }
-        off[pass] = m < P.M ? pix * a.cout + col : -1;
-    }
+    const f32x4 sc = plan.sc, sh = plan.sh;
+    const int(&off)[PASSES] = plan.off;
     if (direct) {
 #pragma unroll
         for (int pass = 0; pass < PASSES; ++pass) {
             if (off[pass] < 0) continue;
             f32x4 v = tile_quad(pass * RPP + r0);
             v = v * sc + sh;
-            if (a.res) v += *(const f32x4 *)(a.res + off[pass]);
+            if constexpr (Plan::PREFETCH_RES) {
+                if (a.res) v += plan.rres[pass];
+            } else {
+                if (a.res) v += *(const f32x4 *)(a.res + off[pass]);
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = apply_act(v[q], a.act);
             *(f32x4 *)(a.out + off[pass]) = v;
@@ -280,7 +314,11 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
     const int tml = fast_div(idx, a.tiles_n_mul, a.tiles_n_shift), tn = idx - tml * a.tiles_n;
     const int m0 = tml * BM, n0 = tn * BN;
     const int sp = blockIdx.z;
-    const int *tab = a.table + ph * PHASE_TABLE_INTS;
+    // The table is read through the constant address space: that keeps its loads scalar whatever
+    // else the kernel does (behind an asm statement or a store the compiler assumes that global
+    // memory may have changed, and falls back to vector loads).
+    typedef const __attribute__((address_space(4))) int *const_int_ptr;
+    const const_int_ptr tab = (const_int_ptr)(uintptr_t)(a.table + ph * PHASE_TABLE_INTS);
     const int ntaps = tab[0];
     PhaseInfo P;
     P.off_y = tab[1];
@@ -395,6 +433,11 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
         }
         GDPSO_SSTORE(0, 0)
     }
+    // What the epilogue reads from the kernel arguments is demanded here, so that it arrives during
+    // the K loop: fetched where first used, each argument costs the epilogue a scalar-load round trip.
+    if constexpr (!FUSE)
+        asm volatile("" ::"s"(a.scale), "s"(a.shift), "s"(a.res), "s"(a.out), "s"(a.part), "s"(a.counters), "s"(a.cout),
+                     "s"(a.hout), "s"(a.wout), "s"(a.out_mul), "s"(a.act), "s"(a.slab));
     __syncthreads();
     GDPSO_STAMP(1)
     // One K-tile.  Within it the 32 k's of a wave are consumed in a permuted order: MFMA step s of
@@ -539,6 +582,8 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
     // in LDS (the K loop's last barrier has retired every operand read).
     constexpr int LDC = BN + 4;
     float *sC = lds;
+    StorePlan<BM, BN> plan;
+    conv_store_plan<BM, BN>(a, tid, m0, n0, P, plan);
     if (KW == 1) {
 #pragma unroll
         for (int i = 0; i < WM; ++i)
@@ -557,7 +602,7 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
             sC[kh * REGION + ((r & 3) + 8 * (r >> 2) + 4 * half) * LDC + wc * 32 + l31] = acc[0][0][r];
     }
     __syncthreads();
-    conv_store_tile<BM, BN, KW>(a, lds, LDS_FLOATS, tid, m0, n0, sp, tile, P);
+    conv_store_tile<BM, BN, KW>(a, lds, LDS_FLOATS, tid, sp, tile, plan);
 #ifdef GDPSO_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have left the CU
     GDPSO_STAMP(3)
