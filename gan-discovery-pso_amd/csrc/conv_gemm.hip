@@ -151,12 +151,10 @@ __device__ __forceinline__ void conv_store_plan(const ConvKArgs &a, int tid, int
 #pragma unroll
     for (int pass = 0; pass < Plan::PASSES; ++pass) {
         const int m = m0 + pass * Plan::RPP + r0;
-        int pix = m;
-        if (remap && m < P.M) {
-            const int n = fast_div(m, P.hw_mul, P.hw_shift), rr = m - n * hw;
-            const int my = fast_div(rr, P.wm_mul, P.wm_shift), mx = rr - my * P.wm;
-            pix = (n * a.hout + my * a.out_mul + P.off_y) * a.wout + mx * a.out_mul + P.off_x;
-        }
+        // straight-line (a branch per pass made the compiler re-fetch its arguments behind every one)
+        const int n = fast_div(m, P.hw_mul, P.hw_shift), rr = m - n * hw;
+        const int my = fast_div(rr, P.wm_mul, P.wm_shift), mx = rr - my * P.wm;
+        const int pix = remap ? (n * a.hout + my * a.out_mul + P.off_y) * a.wout + mx * a.out_mul + P.off_x : m;
         sp.off[pass] = m < P.M ? pix * a.cout + col : -1;
     }
     if constexpr (Plan::PREFETCH_RES) {
@@ -524,12 +522,9 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
             const int m = m0 + pass * 16 + r0;
-            int pix = m;
-            if (remap && m < P.M) {
-                const int n = fast_div(m, P.hw_mul, P.hw_shift), rr = m - n * hw2;
-                const int my = fast_div(rr, P.wm_mul, P.wm_shift), mx = rr - my * P.wm;
-                pix = (n * a.hout + my * a.out_mul + P.off_y) * a.wout + mx * a.out_mul + P.off_x;
-            }
+            const int n = fast_div(m, P.hw_mul, P.hw_shift), rr = m - n * hw2;
+            const int my = fast_div(rr, P.wm_mul, P.wm_shift), mx = rr - my * P.wm;
+            const int pix = remap ? (n * a.hout + my * a.out_mul + P.off_y) * a.wout + mx * a.out_mul + P.off_x : m;
             off[pass] = m < P.M ? pix * f.cout + c4 * 4 : -1;
         }
         const int nblocks = f.cout / 64;
