@@ -72,6 +72,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # Libraries write to stdout too (RCCL prints a version banner there when a process group comes
+    # up): everything but the result line goes to stderr.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -83,7 +89,15 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     comm = None
-    if world > 1:
+    # GDPSO_BENCH_FORCE_COMM=1: a single rank still goes through the process group and the
+    # sharded loop (rehearsal of the RCCL calls on a one-GPU box)
+    force_comm = world == 1 and os.environ.get("GDPSO_BENCH_FORCE_COMM") == "1"
+    if force_comm:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_comm:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
@@ -93,7 +107,7 @@ def main():
     eng = importlib.import_module("gan-discovery-pso_amd.engine")
     synth = importlib.import_module("gan-discovery-pso_amd.synth")
     lib = importlib.import_module("gan-discovery-pso_amd._lib")
-    if world > 1:
+    if world > 1 or force_comm:
         comm = eng.TorchComm()
 
     z_dim, n_class, class_index = args.z_dim, 8, 6
@@ -222,7 +236,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(z_dim, n_class, class_index)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if comm is not None:
         comm.dist.destroy_process_group()
 
