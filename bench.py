@@ -145,18 +145,14 @@ def main():
                 sw.mean_distance(i, sw.pos)
         else:
             deep = os.environ.get("GDPSO_BENCH_DEBUG") == "1"  # any other value: progress lines and the hang dump only
-            for i in range(first, first + count):
-                sw.evaluate(i, spec)
-                if deep: torch.cuda.synchronize(dev); dbg(f"{i} evaluate ok")
-                sw.local_best(i)
-                if deep: torch.cuda.synchronize(dev); dbg(f"{i} local_best ok")
-                comm.all_gather(sw.cand, sw.cand[sw.rank])
-                if deep: torch.cuda.synchronize(dev); dbg(f"{i} all_gather ok")
-                sw.global_best(i, False, False, 1e-5)
-                sw.move(i, 1.496, 1.496, seed=42)
-                if deep: torch.cuda.synchronize(dev); dbg(f"{i} move ok")
-                sw.mean_distance(i, comm.gather_positions(sw.pos, n_global))
-                if deep: torch.cuda.synchronize(dev); dbg(f"{i} distance ok")
+
+            def hook(i, name):
+                if deep:
+                    torch.cuda.synchronize(dev)
+                    dbg(f"{i} {name} ok")
+
+            eng.sharded_iterations(sw, comm, first, count, spec, 1.496, 1.496, False, False, 1e-5, True, seed=42,
+                                   after_phase=hook)
 
     def fence():
         torch.cuda.synchronize(dev)

@@ -465,8 +465,8 @@ def run_loop(swarm, n_iterations, spec, w_cogn, w_soci, *, schedule_inertia=Fals
     ``swarm`` is a HipSwarm (or, in the CPU tests of the sharded protocol, an object with
     the same phase methods).  With ``comm`` (a torch.distributed process group wrapper with
     ``all_gather(out, inp)``) particles are sharded over ranks and the only exchange per
-    iteration is the all-gather of one {value, index, position} record per rank; the
-    optional diagnostic gathers positions as well.  Nothing here synchronises with the
+    iteration is the all-gather of one {value, index, position} record per rank, which the
+    optional diagnostic's positions ride along with (sharded_iterations).  Nothing here synchronises with the
     device except the periodic early-stop poll.
     """
     if comm is None or swarm.n_ranks == 1:
@@ -478,16 +478,41 @@ def run_loop(swarm, n_iterations, spec, w_cogn, w_soci, *, schedule_inertia=Fals
             if early_stopping and i <= n_iterations and int(swarm.control()[_lib.CTRL_STOP_ITER]):
                 break
         return
-    for i in range(1, n_iterations + 1):
+    sharded_iterations(swarm, comm, 1, n_iterations, spec, w_cogn, w_soci, schedule_inertia, early_stopping, tolerance,
+                       diagnostics, seed, poll_every)
+
+
+def sharded_iterations(swarm, comm, first, count, spec, w_cogn, w_soci, schedule_inertia, early_stopping, tolerance,
+                       diagnostics, seed=0, poll_every=8, after_phase=None):
+    """Iterations first .. first+count-1 of the sharded loop, ONE exchange per iteration.
+
+    The diagnostic of iteration i (mean pairwise distance of the positions after its move) needs
+    every rank's positions; they are the positions iteration i+1 starts from, so they travel with
+    the candidate records of iteration i+1 (one coalesced launch), and the diagnostic of the last
+    iteration takes one gather of its own at the end.  ``after_phase(i, name)`` is a debugging hook.
+    """
+    hook = after_phase or (lambda i, name: None)
+    last = 0
+    for i in range(first, first + count):
         swarm.evaluate(i, spec)
+        hook(i, "evaluate")
         swarm.local_best(i)
-        comm.all_gather(swarm.cand, swarm.cand[swarm.rank])
+        hook(i, "local_best")
+        if diagnostics and last:
+            pos_all = comm.all_gather_step(swarm.cand, swarm.cand[swarm.rank], swarm.pos, swarm.n_global)
+            swarm.mean_distance(last, pos_all)
+        else:
+            comm.all_gather(swarm.cand, swarm.cand[swarm.rank])
+        hook(i, "exchange")
         swarm.global_best(i, schedule_inertia, early_stopping, tolerance)
         swarm.move(i, w_cogn, w_soci, seed)
-        if diagnostics:
-            swarm.mean_distance(i, comm.gather_positions(swarm.pos, swarm.n_global))
+        hook(i, "move")
+        last = i
         if early_stopping and i % poll_every == 0 and int(swarm.control()[_lib.CTRL_STOP_ITER]):
             break
+    if diagnostics and last:
+        swarm.mean_distance(last, comm.gather_positions(swarm.pos, swarm.n_global))
+        hook(last, "distance")
 
 
 class TorchComm:
@@ -513,15 +538,16 @@ class TorchComm:
 
     def all_gather(self, out: torch.Tensor, inp: torch.Tensor):
         # out [W, d+2] is the swarm's candidate table; inp is this rank's row of it
-        # (the input is this rank's row of the output: a copy, so that the collective never aliases)
+        self._all_gather_flat(out.view(-1), self._rec_copy(inp).view(-1))
+
+    def _rec_copy(self, inp: torch.Tensor) -> torch.Tensor:
+        # the collective's input is this rank's row of its output: a copy, so that the two never alias
         if getattr(self, "_rec", None) is None or self._rec.shape != inp.shape or self._rec.device != inp.device:
             self._rec = torch.empty_like(inp)
         self._rec.copy_(inp)
-        self._all_gather_flat(out.view(-1), self._rec.view(-1))
+        return self._rec
 
-    def gather_positions(self, pos: torch.Tensor, n_global: int) -> torch.Tensor:
-        """Every rank's positions, in global particle order.  The returned tensor is a buffer of
-        this object that the next call overwrites."""
+    def _pos_buffers(self, pos: torch.Tensor, n_global: int):
         n_max = -(-n_global // self.world)
         d = pos.shape[1]
         key = (n_max, d, pos.dtype, pos.device)
@@ -529,7 +555,26 @@ class TorchComm:
             self._pos_key = key
             self._pos_all = torch.empty(self.world * n_max, d, dtype=pos.dtype, device=pos.device)
             self._pos_pad = torch.zeros(n_max, d, dtype=pos.dtype, device=pos.device)
-        allp = self._pos_all
+        return n_max, self._pos_all
+
+    def all_gather_step(self, cand_out: torch.Tensor, cand_row: torch.Tensor, pos: torch.Tensor, n_global: int) -> torch.Tensor:
+        """The candidate table AND every rank's positions in one exchange: with RCCL and equal
+        shards the two all-gathers are coalesced into one launch; otherwise they run one after
+        the other.  Returns the positions like gather_positions."""
+        n_max, allp = self._pos_buffers(pos, n_global)
+        if self.host_staged or n_global != self.world * n_max or not hasattr(self.dist, "_coalescing_manager"):
+            self.all_gather(cand_out, cand_row)
+            return self.gather_positions(pos, n_global)
+        rec = self._rec_copy(cand_row)
+        with self.dist._coalescing_manager(group=self.group):
+            self.dist.all_gather_into_tensor(cand_out.view(-1), rec.view(-1), group=self.group)
+            self.dist.all_gather_into_tensor(allp.view(-1), pos.reshape(-1), group=self.group)
+        return allp
+
+    def gather_positions(self, pos: torch.Tensor, n_global: int) -> torch.Tensor:
+        """Every rank's positions, in global particle order.  The returned tensor is a buffer of
+        this object that the next call overwrites."""
+        n_max, allp = self._pos_buffers(pos, n_global)
         if n_global == self.world * n_max:  # equal shards: gather straight from the swarm state
             self._all_gather_flat(allp.view(-1), pos.reshape(-1))
             return allp

@@ -218,6 +218,49 @@ def test_logical_shards_match_unsharded(mods):
         np.testing.assert_allclose(r["mean_mse"], g["mean_mse"], rtol=1e-13)
 
 
+def test_sharded_loop_over_rccl(mods):
+    """engine.sharded_iterations through a real RCCL process group (one rank: all this box has):
+    the coalesced candidate + position exchange, the deferred distance diagnostic and the
+    early stop reproduce the reference trajectory bit for bit."""
+    import socket
+    import torch.distributed as dist
+    eng = mods["eng"]
+    g = load_golden("swarm_n64_t50_z10")
+    n, d, iters, t = int(g["n"]), int(g["d"]), g["fitness"].shape[0], int(g["t"])
+    ev = type("E", (), {"device": torch.device("cuda:0"), "gen": type("G", (), {"z_dim": d, "side": 28})()})()
+
+    class Injected(eng.HipSwarm):
+        def evaluate(self, i, spec):  # the reference's own fitness values instead of the networks
+            self.fitness.copy_(torch.from_numpy(g["fitness"][min(i, iters) - 1]))
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda:0"))
+    try:
+        comm = eng.TorchComm()
+        assert not comm.host_staged
+        sw = Injected(ev, n, d, t + 1, first_index=0, n_ranks=1, rank=0, n_global=n)
+        rand = np.concatenate([g["rand"], np.repeat(g["rand"][-1:], t + 1 - iters, axis=0)])
+        sw.load(g["pos"][0], g["vel"][0], float(g["w"][0]), rand=rand)
+        # two calls, as bench.py makes them (warm-up, then the timed steps): the diagnostic of the
+        # first call's last iteration is flushed at its end
+        eng.sharded_iterations(sw, comm, 1, 3, None, float(g["w"][1]), float(g["w"][2]), bool(g["schedule_inertia"]),
+                               bool(g["early_stopping"]), float(g["tolerance"]), True, poll_every=4)
+        eng.sharded_iterations(sw, comm, 4, t - 3, None, float(g["w"][1]), float(g["w"][2]), bool(g["schedule_inertia"]),
+                               bool(g["early_stopping"]), float(g["tolerance"]), True, poll_every=4)
+        res = sw.results()
+    finally:
+        dist.destroy_process_group()
+    assert res["iters"] == iters
+    np.testing.assert_array_equal(res["hist_pos"], g["pos"])
+    np.testing.assert_array_equal(res["g_best_val"], g["g_best_val"])
+    np.testing.assert_array_equal(res["g_best_pos"], g["g_best_pos"])
+    np.testing.assert_allclose(res["mean_mse"], g["mean_mse"], rtol=1e-13)
+
+
 def test_full_size_properties(mods, synth):
     """512 particles x 10 iterations (the benchmark shape) with device-side r1/r2:
     size-independent invariants of the loop."""
