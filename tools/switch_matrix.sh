@@ -1,0 +1,19 @@
+#!/bin/bash
+# The GPU test suite under each development-switch combination (run on the GPU box from the
+# repository root); writes gpurun_out/switch_matrix.txt.  Stops at the first failing run.
+set -e
+OUT=gpurun_out/switch_matrix.txt
+: > $OUT
+run() {
+    echo "== ${*:-defaults}" >> $OUT
+    env "$@" timeout -k 10 300 python3 -u -m pytest tests -m gpu -x -q --timeout 200 --timeout-method thread > gpurun_out/switch_run.log 2>&1 || { tail -n 30 gpurun_out/switch_run.log >> $OUT; exit 1; }
+    tail -n 1 gpurun_out/switch_run.log >> $OUT
+}
+run GDPSO_NONE=1
+run GDPSO_CONV_BORDER_CLASSES=0
+run GDPSO_CONV_TILE32=0
+run GDPSO_CONV_PAIR=0 GDPSO_CONV_FUSE_1X1=0
+run GDPSO_GEN_LAST_MFMA=0 GDPSO_STEM_MFMA=0
+run GDPSO_SPLITK_FUSED_MAX=8 GDPSO_CONV_TILE32=0
+run GDPSO_CONV_SNAKE=0
+cat $OUT
