@@ -154,10 +154,12 @@ constexpr int GL_MAX_KSTEPS = 8;  // cin <= 128
 __global__ __launch_bounds__(512) void gen_last_mfma_kernel(const float *__restrict__ a2, const float *__restrict__ w5,
                                                             float bias, int hin, int cin, float *__restrict__ img,
                                                             float *__restrict__ img01, const float *__restrict__ target,
-                                                            float *__restrict__ mse) {
+                                                            float *__restrict__ mse, FastDiv div_c4, FastDiv div_side) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int side = 2 * hin, npix = side * side, nin = hin * hin;
     const int nblk = (nin + 15) / 16, lda = cin + 4;
+    // n / d by multiply-shift (FastDiv): the chip has no integer divide
+    auto fdiv = [](int v, FastDiv f) { return (int)(((unsigned long long)(unsigned)v * f.mul) >> f.shift); };
     float *s_img = smem;                    // [npix]
     float *s_red = s_img + npix;            // [3][8]
     float *s_c = s_red + 32;                // [nblk * 16][16]
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(512) void gen_last_mfma_kernel(const float *__restr
     const float *src = a2 + (size_t)n * nin * cin;
     const int c4 = cin / 4;
     for (int i = tid; i < nblk * 16 * c4; i += 512) {
-        const int r = i / c4, c = (i - r * c4) * 4;
+        const int r = fdiv(i, div_c4), c = (i - r * c4) * 4;
         f32x4_t v = 0.f;
         if (r < nin) v = *(const f32x4_t *)&src[(size_t)r * cin + c];
         *(f32x4_t *)&s_a2[r * lda + c] = v;
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(512) void gen_last_mfma_kernel(const float *__restr
     float *dst = img ? img + (size_t)n * npix : nullptr;
     const float *tg = target ? target + (size_t)n * npix : nullptr;
     for (int i = tid; i < npix; i += 512) {
-        const int oy = i / side, ox = i - oy * side;
+        const int oy = fdiv(i, div_side), ox = i - oy * side;
         const int py = oy & 1, my = oy >> 1, px = ox & 1, mxx = ox >> 1;
         // (input offset, kernel index) = (0, 1), (-1, 3) for even rows; (0, 2), (+1, 0) for odd; same along x
         const int iy1 = my + (py ? 1 : -1), ky0 = py ? 2 : 1, ky1 = py ? 0 : 3;
@@ -265,10 +267,11 @@ __global__ __launch_bounds__(512) void stem_kernel(const float *__restrict__ img
     const int pr1 = min(hp, pr0 + band);
     const int cr0 = 2 * pr0 - 1, cr1 = 2 * (pr1 - 1) + 1;  // conv rows needed (may stick out)
     const float *src = img01 + (size_t)n * side * side;
-    for (int i = tid; i < prows * ps; i += 512) {
-        const int y = i / ps - 3, x = i % ps - 3;
-        s_img[i] = ((unsigned)y < (unsigned)side && (unsigned)x < (unsigned)side) ? src[y * side + x] : 0.f;
-    }
+    for (int row = tid >> 6; row < prows; row += 8)
+        for (int col = tid & 63; col < ps; col += 64) {
+            const int y = row - 3, x = col - 3;
+            s_img[row * ps + col] = ((unsigned)y < (unsigned)side && (unsigned)x < (unsigned)side) ? src[y * side + x] : 0.f;
+        }
     float wreg[49];
 #pragma unroll
     for (int t = 0; t < 49; ++t) wreg[t] = w[t * 64 + c];
@@ -331,18 +334,22 @@ constexpr int STEM_KSTEPS = 13;  // ceil(49 / 4)
 
 __global__ __launch_bounds__(512) void stem_mfma_kernel(const float *__restrict__ img01, const float *__restrict__ w,
                                                         const float *__restrict__ scale, const float *__restrict__ shift,
-                                                        int side, int ho, int hp, int ps, float *__restrict__ out) {
+                                                        int side, int ho, int hp, int ps, FastDiv div_ho, FastDiv div_hp,
+                                                        float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int prows = side + 6, npx = ho * ho, nblk = (npx + 15) / 16;
+    // n / d by multiply-shift (FastDiv): the chip has no integer divide
+    auto fdiv = [](int v, FastDiv f) { return (int)(((unsigned long long)(unsigned)v * f.mul) >> f.shift); };
     constexpr int LDC = 64 + 4;
     float *s_img = smem;                 // [prows][ps], zero border of 3
     float *s_conv = smem + prows * ps;   // [nblk * 16][LDC]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = blockIdx.x;
     const float *src = img01 + (size_t)n * side * side;
-    for (int i = tid; i < prows * ps; i += 512) {
-        const int y = i / ps - 3, x = i % ps - 3;
-        s_img[i] = ((unsigned)y < (unsigned)side && (unsigned)x < (unsigned)side) ? src[y * side + x] : 0.f;
-    }
+    for (int row = tid >> 6; row < prows; row += 8)
+        for (int col = tid & 63; col < ps; col += 64) {
+            const int y = row - 3, x = col - 3;
+            s_img[row * ps + col] = ((unsigned)y < (unsigned)side && (unsigned)x < (unsigned)side) ? src[y * side + x] : 0.f;
+        }
     // weights [49][64] -> LDS rows of 80 floats (the conv buffer is free until the products start),
     // read with 16-byte loads; the fragment reads below are then conflict-free
     constexpr int LDW = 80;
@@ -372,7 +379,7 @@ __global__ __launch_bounds__(512) void stem_mfma_kernel(const float *__restrict_
     __syncthreads();
     for (int b = wave; b < nblk; b += 8) {
         const int px = min(b * 16 + lrow, npx - 1);  // rows past the image repeat the last pixel; they are never read back
-        const int y = px / ho, x = px - y * ho;
+        const int y = fdiv(px, div_ho), x = px - y * ho;
         const float *base = s_img + (2 * y) * ps + 2 * x;  // padded coordinates: +3 - 3
         float av[STEM_KSTEPS];
 #pragma unroll
@@ -393,7 +400,7 @@ __global__ __launch_bounds__(512) void stem_mfma_kernel(const float *__restrict_
     __syncthreads();
     // MaxPool2d(3, s2, p1); consecutive threads take consecutive channels
     for (int e = tid; e < hp * hp * 64; e += 512) {
-        const int c = e & 63, pp = e >> 6, pr = pp / hp, pc = pp - pr * hp;
+        const int c = e & 63, pp = e >> 6, pr = fdiv(pp, div_hp), pc = pp - pr * hp;
         float m = -INFINITY;
 #pragma unroll
         for (int dy = -1; dy <= 1; ++dy) {
@@ -440,22 +447,35 @@ __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ fea
             pooled[u] = v;
         }
     }
-    for (int k = 0; k < n_class; ++k) {
-        float acc = 0.f;
+    // four classes at a time: their eight weight loads are issued together (one class per trip
+    // of the loop cost a load round trip each); per class the sum runs in the same order as before
+    for (int k0 = 0; k0 < n_class; k0 += 4) {
+        float4 w[4][2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int ch = tid * 4 + u * 1024;
-            if (ch < c) {
-                const float4 w = *(const float4 *)(fc_w + (size_t)k * c + ch);
-                acc = fmaf(pooled[u].x, w.x, acc);
-                acc = fmaf(pooled[u].y, w.y, acc);
-                acc = fmaf(pooled[u].z, w.z, acc);
-                acc = fmaf(pooled[u].w, w.w, acc);
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int ch = tid * 4 + u * 1024;
+                w[j][u] = (k0 + j < n_class && ch < c) ? *(const float4 *)(fc_w + (size_t)(k0 + j) * c + ch)
+                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-        }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-        if (lane == 0) s_part[wave][k] = acc;
+        for (int j = 0; j < 4; ++j) {
+            if (k0 + j >= n_class) break;
+            float acc = 0.f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (tid * 4 + u * 1024 < c) {
+                    acc = fmaf(pooled[u].x, w[j][u].x, acc);
+                    acc = fmaf(pooled[u].y, w[j][u].y, acc);
+                    acc = fmaf(pooled[u].z, w[j][u].z, acc);
+                    acc = fmaf(pooled[u].w, w[j][u].w, acc);
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            if (lane == 0) s_part[wave][k0 + j] = acc;
+        }
     }
     __syncthreads();
     if (tid < n_class) {
@@ -659,7 +679,8 @@ extern "C" int gdpso_generator_forward(const gdpso_generator *g, void *stream_, 
     const int nblk = (hin * hin + 15) / 16;
     const size_t mfma_lds = base + ((size_t)nblk * 16 * 16 + (size_t)nblk * 16 * (g->features + 4)) * sizeof(float);
     if (g->last_mfma && mfma_lds <= g->last_mfma_lds_max)
-        hipLaunchKernelGGL(gen_last_mfma_kernel, dim3(n), dim3(512), mfma_lds, stream, a2, g->w5, g->b5, hin, g->features, img, img01, target, mse);
+        hipLaunchKernelGGL(gen_last_mfma_kernel, dim3(n), dim3(512), mfma_lds, stream, a2, g->w5, g->b5, hin, g->features, img, img01, target, mse,
+                           fast_div_for((unsigned)(g->features / 4)), fast_div_for((unsigned)(2 * hin)));
     else if (staged <= 64 * 1024)
         hipLaunchKernelGGL(gen_last_kernel<true>, dim3(n), dim3(512), staged, stream, a2, g->w5, g->b5, hin, g->features, img, img01, target, mse);
     else
@@ -831,7 +852,7 @@ extern "C" int gdpso_assessor_forward(const gdpso_assessor *a, void *stream_, in
     const size_t mfma_smem = ((size_t)(a->side + 6) * mps + (size_t)((a->ho * a->ho + 15) / 16 * 16) * 68) * sizeof(float);
     if (stem_mfma && mfma_smem <= 64 * 1024) {
         hipLaunchKernelGGL(stem_mfma_kernel, dim3(n), dim3(512), mfma_smem, stream, img01, a->stem_w, a->stem_scale, a->stem_shift,
-                           a->side, a->ho, a->hp, mps, x);
+                           a->side, a->ho, a->hp, mps, fast_div_for((unsigned)a->ho), fast_div_for((unsigned)a->hp), x);
     } else {
         const int rows = 2 * a->stem_band + 1;
         const size_t smem = ((size_t)(a->side + 6) * a->stem_ps + (size_t)rows * a->ho * 64) * sizeof(float);
