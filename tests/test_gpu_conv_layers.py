@@ -130,3 +130,30 @@ def test_rejects_bad_arguments(lib):
     # null input
     assert call(1, 4, 32, 64, 1, 1, 0, 0, 0, 0, 0, w.ctypes.data, v.ctypes.data, v.ctypes.data, 0, 0,
                 out.data_ptr(), None, None) != 0
+
+
+def test_random_layer_shapes(lib):
+    """Seeded sweep over window sizes, strides, paddings, map sizes, channel counts, tile shapes
+    and split counts (the encoder's k4 s2 p1 and the 5x5 / 7x7 windows among them)."""
+    rng = np.random.default_rng(2024)
+    done = 0
+    while done < 48:
+        k = int(rng.choice([1, 2, 3, 4, 5, 7]))
+        stride = int(rng.choice([1, 2, 3]))
+        pad = int(rng.integers(0, k // 2 + 1))
+        hin = int(rng.integers(max(1, k - 2 * pad), 12))
+        cin = int(rng.choice([32, 64, 128, 160, 256]))
+        cout = int(rng.choice([64, 128, 192]))
+        n = int(rng.integers(1, 6))
+        tiles = [T64] + ([T32] if cin % 64 == 0 else []) + ([T16] if cin % 128 == 0 else []) + ([T128] if cout % 128 == 0 else [])
+        tile = int(rng.choice(tiles))
+        splits = int(rng.choice([1, 1, 2, 3]))
+        act = int(rng.integers(0, 3))
+        with_res = bool(rng.integers(0, 2))
+        try:
+            run_layer(lib, n, hin, cin, cout, k, stride, pad, False, act=act, tile=tile, splits=splits, with_res=with_res,
+                      seed=1000 + done)
+        except AssertionError as e:
+            raise AssertionError(f"case n={n} hin={hin} cin={cin} cout={cout} k={k} stride={stride} pad={pad} tile={tile} "
+                                 f"splits={splits} act={act} res={with_res}: {e}") from e
+        done += 1
