@@ -65,10 +65,11 @@ struct ConvKArgs {
     int act, splits;
     int tiles_n;
     long slab;  // elements per split-K slab
-    int phase_tiles[MAX_PHASES];  // tiles (M-tiles x column tiles) of each phase
-    int phase_end[MAX_PHASES];    // running sum over phases of ceil(phase_tiles / 8) (INT_MAX past the last)
+    // Per phase: (running sum over phases of ceil(tiles / 8), the phase's tiles being M-tiles x column
+    // tiles) | (8 * ceil(tiles / 8) - tiles) << 24; 0xffffff past the last phase.
+    unsigned phase_word[MAX_PHASES];
     unsigned tiles_n_mul, tiles_n_shift;  // FastDiv by tiles_n
-    int per_xcd;                  // workgroups of this layer per XCD (= the last phase_end)
+    int per_xcd;                  // workgroups of this layer per XCD (= the last phase's running end)
     int snake;                    // CUs per XCD when the second round of workgroups is dealt in reverse, else 0
 };
 
@@ -106,12 +107,12 @@ __device__ __attribute__((aligned(128))) float g_zero_page[MAX_CIN + 32] = {};
 __device__ unsigned long long *g_stamps = nullptr;
 #define GDPSO_STAMP(SLOT)                                                                   \
     if (g_stamps && threadIdx.x == 0) {                                                     \
-        g_stamps[(size_t)blockIdx.x * 8 + (SLOT)] = __builtin_amdgcn_s_memtime();           \
-        if ((SLOT) == 0) g_stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime(); \
+        g_stamps[(size_t)blockIdx.x * 16 + (SLOT)] = __builtin_amdgcn_s_memtime();           \
+        if ((SLOT) == 0) g_stamps[(size_t)blockIdx.x * 16 + 7] = __builtin_amdgcn_s_memrealtime(); \
         if ((SLOT) == 0)                                                                    \
-            g_stamps[(size_t)blockIdx.x * 8 + 5] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | /* HW_REG_HW_ID */ \
+            g_stamps[(size_t)blockIdx.x * 16 + 5] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | /* HW_REG_HW_ID */ \
                                                    ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32); /* HW_REG_XCC_ID */ \
-        if ((SLOT) == 3) g_stamps[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime(); \
+        if ((SLOT) == 3) g_stamps[(size_t)blockIdx.x * 16 + 6] = __builtin_amdgcn_s_memrealtime(); \
     }
 #else
 #define GDPSO_STAMP(SLOT)
@@ -292,22 +293,39 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
     // weight columns hit the same L2; of every phase, because phases differ in cost (a border
     // class has fewer taps than the interior) and an XCD holding only interior tiles would finish
     // last.  A phase's tile count is rounded up to a multiple of 8; the surplus workgroups exit.
+    // Everything the prologue reads from the kernel arguments is demanded here, in one statement
+    // (30 operands at most): fetched where first used, the arguments cost the prologue a chain of
+    // scalar-load round trips of ~0.25 us each ahead of the first operand load.
+#define GDPSO_W(I) "s"(a.phase_word[I])
+    static_assert(MAX_PHASES == 16, "the operand list names 16 phases");
+    asm volatile("" ::"s"(a.in), "s"(a.wt), "s"(a.table), "s"(a.n_images), "s"(a.hin), "s"(a.win), "s"(a.cin),
+                 "s"(a.in_stride), "s"(a.splits), "s"(a.tiles_n), "s"(a.per_xcd), "s"(a.snake), "s"(a.tiles_n_mul),
+                 "s"(a.tiles_n_shift), GDPSO_W(0), GDPSO_W(1), GDPSO_W(2), GDPSO_W(3), GDPSO_W(4), GDPSO_W(5), GDPSO_W(6),
+                 GDPSO_W(7), GDPSO_W(8), GDPSO_W(9), GDPSO_W(10), GDPSO_W(11), GDPSO_W(12), GDPSO_W(13), GDPSO_W(14),
+                 GDPSO_W(15));
+#undef GDPSO_W
     const int xcd = bx & 7;
     int slot = bx >> 3;
     // An XCD deals its workgroups round-robin to its CUs: with two per CU and phases in order of
     // decreasing cost, CU i would get the i-th heaviest and the (i + CUs)-th heaviest.  Dealing the
     // second round from the light end pairs heavy with light.
     if (a.snake && slot >= a.snake) slot = a.per_xcd - 1 - (slot - a.snake);
+    // The phase of this slot: the first whose running end exceeds it.  The ends increase, so
+    // `past` holds for p < ph exactly and the xor chain telescopes to phase_word[ph] (a chain of
+    // selects over the array would be turned into a load indexed by ph, from a scratch copy).
     int ph = 0, base = 0;
+    unsigned sel = a.phase_word[0];
 #pragma unroll
-    for (int p = 0; p < MAX_PHASES - 1; ++p)
-        if (slot >= a.phase_end[p]) {
-            ph = p + 1;
-            base = a.phase_end[p];
-        }
-    const int per_xcd = a.phase_end[ph] - base;
+    for (int p = 0; p < MAX_PHASES - 1; ++p) {
+        const int end_p = (int)(a.phase_word[p] & 0xffffffu);
+        const bool past = slot >= end_p;
+        ph += past ? 1 : 0;
+        base = max(base, past ? end_p : 0);
+        sel ^= past ? (a.phase_word[p + 1] ^ a.phase_word[p]) : 0u;
+    }
+    const int per_xcd = (int)(sel & 0xffffffu) - base;
     const int idx = xcd * per_xcd + (slot - base);
-    if (idx >= a.phase_tiles[ph]) return;
+    if (idx >= 8 * per_xcd - (int)(sel >> 24)) return;
     const int tile = bx;
     const int tml = fast_div(idx, a.tiles_n_mul, a.tiles_n_shift), tn = idx - tml * a.tiles_n;
     const int m0 = tml * BM, n0 = tn * BN;
@@ -329,6 +347,10 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
     P.hw_shift = (unsigned)tab[11] & 0xff;
     P.wm_shift = ((unsigned)tab[11] >> 8) & 0xff;
     const int in_y0 = tab[6], in_x0 = tab[7], wstride = tab[8];
+#ifdef GDPSO_STAMPS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(wstride), "s"(ntaps) : "memory");  // the phase header has arrived
+    GDPSO_STAMP(8)
+#endif
     const float *wt = a.wt + tab[3];
     const int ktot = ntaps * a.cin;
     // this phase's K range per split (the divide only where K is split at all)
@@ -429,6 +451,11 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
         if constexpr (PF2) {
             if (nk > 1) GDPSO_GLOAD(1)
         }
+#ifdef GDPSO_STAMPS
+        GDPSO_STAMP(9)  // first loads issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GDPSO_STAMP(10)  // ... and returned
+#endif
         GDPSO_SSTORE(0, 0)
     }
     // What the epilogue reads from the kernel arguments is demanded here, so that it arrives during
@@ -772,12 +799,16 @@ static int conv_args(const ConvLayer &L, int n_images, const float *in, const fl
     a.n_images = n_images;
     long per_xcd = 0;
     for (int p = 0; p < MAX_PHASES; ++p) {
-        a.phase_tiles[p] = p < L.nphase ? (int)(ceil_div((long)n_images * L.phase[p].hm * L.phase[p].wm, tile_bm(L.tile)) *
-                                                (L.cout / tile_bn(L.tile)))
-                                        : 0;
-        if (p < L.nphase) per_xcd += ceil_div(a.phase_tiles[p], 8);
-        a.phase_end[p] = p < L.nphase ? (int)per_xcd : 0x7fffffff;
+        if (p >= L.nphase) {
+            a.phase_word[p] = 0xffffffu;
+            continue;
+        }
+        const long tiles = (long)ceil_div((long)n_images * L.phase[p].hm * L.phase[p].wm, tile_bm(L.tile)) * (L.cout / tile_bn(L.tile));
+        const long eighth = ceil_div(tiles, 8);
+        per_xcd += eighth;
+        a.phase_word[p] = (unsigned)per_xcd | ((unsigned)(8 * eighth - tiles) << 24);
     }
+    if (per_xcd >= 0xffffff) return fail(GDPSO_ERR_ARG, "conv: too many tiles");
     *grid_x = 8 * per_xcd;
     a.per_xcd = (int)per_xcd;
     a.snake = (g_snake && L.nphase > 1 && per_xcd > g_cus_per_xcd && per_xcd <= 2 * g_cus_per_xcd) ? g_cus_per_xcd : 0;

@@ -37,7 +37,7 @@ def main():
     lib.gdpso_last_error.restype = C.c_char_p
     lib.gdpso_conv_probe.argtypes = [C.c_int] * 11 + [C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.gdpso_conv_stamps_set.argtypes = [C.c_void_p]
-    buf = torch.zeros(1 << 16, 8, dtype=torch.int64, device="cuda")
+    buf = torch.zeros(1 << 16, 16, dtype=torch.int64, device="cuda")
     assert lib.gdpso_conv_stamps_set(buf.data_ptr()) == 0, lib.gdpso_last_error()
     us, tile, splits = C.c_double(), C.c_int(), C.c_int()
     rc = lib.gdpso_conv_probe(*a, 5, C.byref(us), C.byref(tile), C.byref(splits))
@@ -55,6 +55,11 @@ def main():
     print(f"workgroup start: median {np.median(start):.2f} us, last {start.max():.2f} us; last exit {end.max():.2f} us after the first entry")
     for name, v in zip(("prologue (to first K-tile in LDS)", "K loop", "epilogue (to stores drained)"), ph):
         print(f"  {name:36s} median {np.median(v):6.2f} us   p90 {np.percentile(v, 90):6.2f}   max {v.max():6.2f}")
+    if (s[:, 8] != 0).all():
+        for name, a, b in (("  entry -> phase header in SGPRs", 0, 8), ("  -> first K-tile loads issued", 8, 9),
+                           ("  -> loads returned", 9, 10), ("  -> LDS stores + barrier", 10, 1)):
+            v = (s[:, b] - s[:, a]) / (ghz * 1e3)
+            print(f"  {name:36s} median {np.median(v):6.2f} us   p90 {np.percentile(v, 90):6.2f}   max {v.max():6.2f}")
     life = (s[:, 3] - s[:, 0]) / (ghz * 1e3)
     print(f"  workgroup lifetime                   median {np.median(life):6.2f} us   max {life.max():6.2f}")
     # placement: HW_REG_HW_ID (cu_id bits 11:8, sh_id 12, se_id 15:13) and HW_REG_XCC_ID per workgroup
