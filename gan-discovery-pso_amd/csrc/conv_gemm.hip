@@ -315,13 +315,16 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
     // selects over the array would be turned into a load indexed by ph, from a scratch copy).
     int ph = 0, base = 0;
     unsigned sel = a.phase_word[0];
+    if (a.phase_word[1] != 0xffffffu) {  // single-phase layers (every 1x1 convolution) have nothing to search
 #pragma unroll
-    for (int p = 0; p < MAX_PHASES - 1; ++p) {
-        const int end_p = (int)(a.phase_word[p] & 0xffffffu);
-        const bool past = slot >= end_p;
-        ph += past ? 1 : 0;
-        base = max(base, past ? end_p : 0);
-        sel ^= past ? (a.phase_word[p + 1] ^ a.phase_word[p]) : 0u;
+        for (int p = 0; p < MAX_PHASES - 1; ++p) {
+            const int end_p = (int)(a.phase_word[p] & 0xffffffu);
+            // integer forms throughout, so that the chain stays on the scalar unit
+            const int past = (int)((unsigned)(end_p - 1 - slot) >> 31);  // slot >= end_p
+            ph += past;
+            base = max(base, end_p & -past);
+            sel ^= (a.phase_word[p + 1] ^ a.phase_word[p]) & (unsigned)-past;
+        }
     }
     const int per_xcd = (int)(sel & 0xffffffu) - base;
     const int idx = xcd * per_xcd + (slot - base);
@@ -336,6 +339,7 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
     typedef const __attribute__((address_space(4))) int *const_int_ptr;
     const const_int_ptr tab = (const_int_ptr)(uintptr_t)(a.table + ph * PHASE_TABLE_INTS);
     const int ntaps = tab[0];
+    const int tap0_packed = tab[PHASE_HDR];  // read with the header: one scalar-load round trip fewer
     PhaseInfo P;
     P.off_y = tab[1];
     P.off_x = tab[2];
@@ -384,9 +388,9 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
 #pragma unroll
     for (int p = 0; p < PB; ++p) brow[p] = wt + ((n0 + lrow + RP * p) * wstride + lcol);  // 32-bit offsets: see conv_args
     int tap = a.splits == 1 ? 0 : kbeg / a.cin, ci0 = kbeg - tap * a.cin;
-#define GDPSO_SET_TAP(CI)                                                                                       \
+#define GDPSO_SET_TAP(CI, PACKED)                                                                               \
     {                                                                                                           \
-        const int packed_ = tab[PHASE_HDR + tap];                                                               \
+        const int packed_ = (PACKED);                                                                           \
         const int dy_ = (int)(signed char)(packed_ & 0xff), dx_ = (int)(signed char)((packed_ >> 8) & 0xff);    \
         const int wk_ = (packed_ >> 16) * a.cin + (CI);                                                         \
         _Pragma("unroll") for (int p = 0; p < PA; ++p) {                                                        \
@@ -419,7 +423,7 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
         ci0 += BKT;                                                                                             \
         if (ci0 == a.cin) {                                                                                     \
             ci0 = 0;                                                                                            \
-            if (++tap < ntaps) GDPSO_SET_TAP(0)                                                                 \
+            if (++tap < ntaps) GDPSO_SET_TAP(0, tab[PHASE_HDR + tap])                                           \
         }                                                                                                       \
     }
 #define GDPSO_SSTORE(BUF, S)                                                                                    \
@@ -446,7 +450,7 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
 
     const int nk = kbeg < kend ? (kend - kbeg) / BKT : 0;  // K-tiles of this workgroup
     if (nk > 0) {
-        GDPSO_SET_TAP(ci0)
+        GDPSO_SET_TAP(ci0, tap == 0 ? tap0_packed : tab[PHASE_HDR + tap])
         GDPSO_GLOAD(0)
         if constexpr (PF2) {
             if (nk > 1) GDPSO_GLOAD(1)
