@@ -452,15 +452,17 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
     if (nk > 0) {
         GDPSO_SET_TAP(ci0, tap == 0 ? tap0_packed : tab[PHASE_HDR + tap])
         GDPSO_GLOAD(0)
-        if constexpr (PF2) {
-            if (nk > 1) GDPSO_GLOAD(1)
-        }
 #ifdef GDPSO_STAMPS
         GDPSO_STAMP(9)  // first loads issued
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         GDPSO_STAMP(10)  // ... and returned
 #endif
         GDPSO_SSTORE(0, 0)
+        // the second K-tile only now: issued ahead of the first one's LDS stores it would share the
+        // CU's 64 B/clk load path with it and delay the first MFMA
+        if constexpr (PF2) {
+            if (nk > 1) GDPSO_GLOAD(1)
+        }
     }
     // What the epilogue reads from the kernel arguments is demanded here, so that it arrives during
     // the K loop: fetched where first used, each argument costs the epilogue a scalar-load round trip.
