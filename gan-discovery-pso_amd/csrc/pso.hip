@@ -255,14 +255,8 @@ __global__ __launch_bounds__(256) void move_kernel(gdpso_swarm s, int iteration,
 // workgroup barriers instead of kernel boundaries.  Same device functions, same results.
 constexpr int SMALL_THREADS = 1024;
 constexpr int SMALL_MAX_N = 4096;
-__global__ __launch_bounds__(SMALL_THREADS) void swarm_step_small_kernel(gdpso_swarm s, int iteration, int schedule_inertia,
-                                                                         int early_stopping, double tolerance, double w_cogn,
-                                                                         double w_soci, const double *__restrict__ rnd,
-                                                                         uint64_t seed, int f32_terms) {
-    __shared__ unsigned char s_better[SMALL_MAX_N];
-    __shared__ BestRec s_best[SMALL_THREADS / 64];
-    __shared__ int s_take;
-    if (!running(s.ctrl, iteration)) return;
+// Personal bests and this rank's candidate record (slot rank_slot of s.cand), one workgroup.
+__device__ __forceinline__ void small_local_phase(const gdpso_swarm &s, int rank_slot, unsigned char *s_better, BestRec *s_best) {
     const int tid = threadIdx.x;
     // update_personal_best
     BestRec r;
@@ -294,13 +288,26 @@ __global__ __launch_bounds__(SMALL_THREADS) void swarm_step_small_kernel(gdpso_s
     __threadfence_block();
     __syncthreads();
     // this swarm's candidate record
-    double *rec = s.cand;
+    double *rec = s.cand + (size_t)rank_slot * (s.d + 2);
     const bool have = r.idx != 0x7fffffff && r.val < INFINITY;
     if (tid == 0) {
         rec[0] = have ? (double)r.val : (double)INFINITY;
         rec[1] = have ? (double)r.idx : -1.0;
     }
     for (int k = tid; k < s.d; k += SMALL_THREADS) rec[2 + k] = have ? s.pbest_pos[(size_t)(r.idx - s.first_index) * s.d + k] : 0.0;
+}
+
+__global__ __launch_bounds__(SMALL_THREADS) void swarm_step_small_kernel(gdpso_swarm s, int iteration, int schedule_inertia,
+                                                                         int early_stopping, double tolerance, double w_cogn,
+                                                                         double w_soci, const double *__restrict__ rnd,
+                                                                         uint64_t seed, int f32_terms) {
+    __shared__ unsigned char s_better[SMALL_MAX_N];
+    __shared__ BestRec s_best[SMALL_THREADS / 64];
+    __shared__ int s_take;
+    if (!running(s.ctrl, iteration)) return;
+    const int tid = threadIdx.x;
+    small_local_phase(s, 0, s_better, s_best);
+    const double *rec = s.cand;
     __threadfence_block();
     __syncthreads();
     // update_global_best, inertia decay, early-stopping test
@@ -311,8 +318,17 @@ __global__ __launch_bounds__(SMALL_THREADS) void swarm_step_small_kernel(gdpso_s
     __threadfence_block();
     __syncthreads();
     // move_particles
+    const long nd = (long)s.n * s.d;
     const double w = s.ctrl[GDPSO_CTRL_W];
     for (long e = tid; e < nd; e += SMALL_THREADS) move_element(s, iteration, e, w, w_cogn, w_soci, rnd, seed, f32_terms);
+}
+
+// The local half alone, for the sharded loop (the exchange of the candidate records follows it).
+__global__ __launch_bounds__(SMALL_THREADS) void swarm_local_small_kernel(gdpso_swarm s, int iteration, int rank_slot) {
+    __shared__ unsigned char s_better[SMALL_MAX_N];
+    __shared__ BestRec s_best[SMALL_THREADS / 64];
+    if (!running(s.ctrl, iteration)) return;
+    small_local_phase(s, rank_slot, s_better, s_best);
 }
 
 // Swarm.mse (util_pso.py:76-86): mean Euclidean distance over unordered pairs.  Tile of
@@ -426,6 +442,11 @@ extern "C" int gdpso_swarm_local_best(const gdpso_swarm *s, void *stream, int it
     GDPSO_REQUIRE(iteration >= 1 && iteration <= s->max_iter, "swarm_local_best: iteration out of range");
     GDPSO_REQUIRE(rank_slot >= 0 && rank_slot < s->n_ranks, "swarm_local_best: rank_slot out of range");
     GDPSO_REQUIRE(gdpso_swarm_scratch_bytes(s->n) <= s->scratch_bytes, "swarm_local_best: scratch too small");
+    if (s->n <= SMALL_MAX_N && (long)s->n * s->d <= 64L * SMALL_THREADS) {  // one workgroup does both steps
+        hipLaunchKernelGGL(swarm_local_small_kernel, dim3(1), dim3(SMALL_THREADS), 0, (hipStream_t)stream, *s, iteration, rank_slot);
+        GDPSO_HIP(hipGetLastError());
+        return GDPSO_OK;
+    }
     BestRec *partial = (BestRec *)s->scratch;
     const int nb = ceil_div(s->n, PB);
     hipLaunchKernelGGL(pbest_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *s, iteration, partial);

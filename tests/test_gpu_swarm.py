@@ -218,6 +218,49 @@ def test_logical_shards_match_unsharded(mods):
         np.testing.assert_allclose(r["mean_mse"], g["mean_mse"], rtol=1e-13)
 
 
+def test_many_particles_take_the_multi_workgroup_kernels(mods):
+    """More particles than the one-workgroup kernels take (4096): personal bests, candidate record,
+    global best and move through pbest_kernel / candidate_kernel / global_best_kernel / move_kernel,
+    against numpy float64 on the same fitness values and r1/r2."""
+    eng = mods["eng"]
+    n, d, iters = 5000, 10, 4
+    rs = np.random.RandomState(17)
+    pos, vel = rs.standard_normal((n, d)), rs.standard_normal((n, d)) * 0.1
+    fit = rs.random_sample((iters, n)).astype(np.float32)
+    fit[1, 100] = fit[1, 4000] = np.float32(-1.0)  # a tie between two workgroups: the lower index wins
+    rand = rs.random_sample((iters, n, 2))
+    w, wc, ws_ = 0.73, 1.496, 1.3
+    ev = type("E", (), {"device": torch.device("cuda:0"), "gen": type("G", (), {"z_dim": d, "side": 28})()})()
+    sw = object.__new__(eng.HipSwarm)
+    eng.HipSwarm.__init__(sw, ev, n, d, iters, diagnostics=False)
+    sw.load(pos, vel, w, rand=rand)
+    pb_val, pb_pos = np.full(n, np.inf, np.float32), pos.copy()
+    g_val, g_pos = np.float32(np.inf), np.zeros(d)
+    for i in range(1, iters + 1):
+        sw.fitness.copy_(torch.from_numpy(fit[i - 1]))
+        sw.local_best(i)
+        sw.global_best(i, False, False, 1e-5)
+        sw.move(i, wc, ws_)
+        better = fit[i - 1] < pb_val
+        pb_val = np.where(better, fit[i - 1], pb_val)
+        pb_pos = np.where(better[:, None], pos, pb_pos)
+        k = int(np.argmin(pb_val))
+        if pb_val[k] < g_val:
+            g_val, g_pos = pb_val[k], pb_pos[k].copy()
+        r1, r2 = rand[i - 1][:, 0:1], rand[i - 1][:, 1:2]
+        vel = (w * vel + (ws_ * r2) * (pb_pos - pos)) + (wc * r1) * (g_pos[None] - pos)
+        pos = pos + vel
+        cand = sw.cand.cpu().numpy()[0]
+        assert cand[0] == pb_val[k] and int(cand[1]) == k
+    res = sw.results()
+    assert res["gbest_val"] == g_val and res["gbest_idx"] == 100
+    np.testing.assert_array_equal(res["pbest_val"], pb_val)
+    np.testing.assert_array_equal(res["pbest_pos"], pb_pos)
+    np.testing.assert_array_equal(res["g_best_pos"], g_pos)
+    np.testing.assert_array_equal(res["pos"], pos)
+    np.testing.assert_array_equal(res["vel"], vel)
+
+
 def test_sharded_loop_over_rccl(mods):
     """engine.sharded_iterations through a real RCCL process group (one rank: all this box has):
     the coalesced candidate + position exchange, the deferred distance diagnostic and the
