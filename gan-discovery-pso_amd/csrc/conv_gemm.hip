@@ -105,6 +105,9 @@ __device__ __attribute__((aligned(128))) float g_zero_page[MAX_CIN + 32] = {};
 #ifdef GDPSO_STAMPS
 // Diagnostic build only (tools/stamp_probe.py): per-workgroup time stamps of the tile code.
 __device__ unsigned long long *g_stamps = nullptr;
+// bit 0: skip the MFMAs of the K loop, bit 1: skip its global loads, bit 2: skip its LDS stores
+// (what is left shows what the skipped part costs; results are garbage)
+__device__ int g_dbg_skip = 0;
 #define GDPSO_STAMP(SLOT)                                                                   \
     if (g_stamps && threadIdx.x == 0) {                                                     \
         g_stamps[(size_t)blockIdx.x * 16 + (SLOT)] = __builtin_amdgcn_s_memtime();           \
@@ -410,21 +413,27 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
     constexpr bool PF2 = WM * WN == 1;
     constexpr int NSET = PF2 ? 2 : 1;
     f32x4 ra[NSET][PA], rb[NSET][PB];
-#define GDPSO_GLOAD(S)                                                                                          \
+    // A K-tile's loads (straight-line, so that a K-step can interleave them with its MFMAs) and,
+    // separately, the move of the gather pointers to the next K-tile (which branches at a tap change).
+#define GDPSO_GISSUE(S)                                                                                         \
     {                                                                                                           \
-        _Pragma("unroll") for (int p = 0; p < PA; ++p) {                                                        \
-            ra[S][p] = *(global_f32x4_ptr)aptr[p];                                                               \
-            aptr[p] += BKT;                                                                                     \
-        }                                                                                                       \
-        _Pragma("unroll") for (int p = 0; p < PB; ++p) {                                                        \
-            rb[S][p] = *(global_f32x4_ptr)bptr[p];                                                               \
-            bptr[p] += BKT;                                                                                     \
-        }                                                                                                       \
+        _Pragma("unroll") for (int p = 0; p < PA; ++p) ra[S][p] = *(global_f32x4_ptr)aptr[p];                    \
+        _Pragma("unroll") for (int p = 0; p < PB; ++p) rb[S][p] = *(global_f32x4_ptr)bptr[p];                    \
+    }
+#define GDPSO_GADVANCE()                                                                                        \
+    {                                                                                                           \
+        _Pragma("unroll") for (int p = 0; p < PA; ++p) aptr[p] += BKT;                                          \
+        _Pragma("unroll") for (int p = 0; p < PB; ++p) bptr[p] += BKT;                                          \
         ci0 += BKT;                                                                                             \
         if (ci0 == a.cin) {                                                                                     \
             ci0 = 0;                                                                                            \
             if (++tap < ntaps) GDPSO_SET_TAP(0, tab[PHASE_HDR + tap])                                           \
         }                                                                                                       \
+    }
+#define GDPSO_GLOAD(S)                                                                                          \
+    {                                                                                                           \
+        GDPSO_GISSUE(S)                                                                                         \
+        GDPSO_GADVANCE()                                                                                        \
     }
 #define GDPSO_SSTORE(BUF, S)                                                                                    \
     {                                                                                                           \
@@ -478,30 +487,66 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
     // registers to the other LDS buffer ahead of the last group, in the shadow of the MFMAs that
     // are still executing, instead of after them.  The sched_group_barrier sequence pins that
     // order (0x100 = DS read, 0x200 = DS write, 0x008 = MFMA).
+#ifdef GDPSO_STAMPS
+    const int dbg_skip = g_dbg_skip;
+#define GDPSO_DBG(BIT) (!(dbg_skip & (BIT)))
+#else
+#define GDPSO_DBG(BIT) true
+#endif
+    // Waves with one MFMA block (16 MFMAs a K-step) take the pinning further: every other
+    // instruction of the step sits between two MFMAs of the dependent chain, where it issues while
+    // the previous MFMA executes: the K-tile's global loads behind MFMAs 1-3 and 5-7, the fragment
+    // reads behind 0, 4 and 8, the LDS stores behind 9-12, so that they have drained when the
+    // last MFMA issues and the barrier follows it directly.  With a single wave per SIMD (one
+    // workgroup per CU) nothing else would cover them: measured there, the loads, the stores and the
+    // MFMAs of a K-step simply added up.
+#define GDPSO_SGB(MASK, N) \
+    if ((N) > 0) __builtin_amdgcn_sched_group_barrier(MASK, (N) > 0 ? (N) : 1, 0);
 #define GDPSO_KSTEP(LOAD, LS, MORE, SS)                                                                         \
     {                                                                                                           \
-        if (LOAD) GDPSO_GLOAD(LS)                                                                               \
+        if ((LOAD) && GDPSO_DBG(2)) GDPSO_GISSUE(LS)                                                            \
         const float *pa = sA + buf * BM * LDA + (wr * (BM / 2) + l31) * LDA + half * 4 + kh * 32;               \
         const float *pb = sB + buf * BN * LDA + (wc * (BN / 2) + l31) * LDA + half * 4 + kh * 32;               \
         f32x4 av[2][WM], bv[2][WN];                                                                             \
         GDPSO_LOADFRAG(0, 0)                                                                                    \
         _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                         \
             if (g < 3) GDPSO_LOADFRAG((g + 1) & 1, g + 1)                                                       \
-            if (g == 3 && (MORE)) GDPSO_SSTORE(buf ^ 1, SS)                                                     \
+            if (g == 3 && (MORE) && GDPSO_DBG(4)) GDPSO_SSTORE(buf ^ 1, SS)                                     \
             _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                       \
                 _Pragma("unroll") for (int i = 0; i < WM; ++i)                                                  \
                     _Pragma("unroll") for (int j = 0; j < WN; ++j)                                              \
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1][i][s], bv[g & 1][j][s], acc[i][j], 0, 0, 0); \
+                        if (GDPSO_DBG(1))                                                                       \
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1][i][s], bv[g & 1][j][s], acc[i][j], 0, 0, 0); \
         }                                                                                                       \
-        __builtin_amdgcn_sched_group_barrier(0x100, WM + WN, 0);                                                \
-        _Pragma("unroll") for (int g = 0; g < 3; ++g) {                                                         \
+        if constexpr (WM * WN == 1) {                                                                           \
+            constexpr int NV = (LOAD) ? PA + PB : 0, NW = (MORE) ? PA + PB : 0;                                 \
+            GDPSO_SGB(0x100, 2)                                                                                 \
+            GDPSO_SGB(0x008, 1) GDPSO_SGB(0x100, 2)                                                             \
+            GDPSO_SGB(0x008, 1) GDPSO_SGB(0x020, (NV + 5) / 6)                                                  \
+            GDPSO_SGB(0x008, 1) GDPSO_SGB(0x020, (NV + 4) / 6)                                                  \
+            GDPSO_SGB(0x008, 1) GDPSO_SGB(0x020, (NV + 3) / 6)                                                  \
+            GDPSO_SGB(0x008, 1) GDPSO_SGB(0x100, 2)                                                             \
+            GDPSO_SGB(0x008, 1) GDPSO_SGB(0x020, (NV + 2) / 6)                                                  \
+            GDPSO_SGB(0x008, 1) GDPSO_SGB(0x020, (NV + 1) / 6)                                                  \
+            GDPSO_SGB(0x008, 1) GDPSO_SGB(0x020, NV / 6)                                                        \
+            GDPSO_SGB(0x008, 1) GDPSO_SGB(0x100, 2)                                                             \
+            GDPSO_SGB(0x008, 1) GDPSO_SGB(0x200, (NW + 3) / 4)                                                  \
+            GDPSO_SGB(0x008, 1) GDPSO_SGB(0x200, (NW + 2) / 4)                                                  \
+            GDPSO_SGB(0x008, 1) GDPSO_SGB(0x200, (NW + 1) / 4)                                                  \
+            GDPSO_SGB(0x008, 1) GDPSO_SGB(0x200, NW / 4)                                                        \
+            GDPSO_SGB(0x008, 3)                                                                                 \
+        } else {                                                                                                \
             __builtin_amdgcn_sched_group_barrier(0x100, WM + WN, 0);                                            \
+            _Pragma("unroll") for (int g = 0; g < 3; ++g) {                                                     \
+                __builtin_amdgcn_sched_group_barrier(0x100, WM + WN, 0);                                        \
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * WM * WN, 0);                                    \
+            }                                                                                                   \
+            if (MORE) __builtin_amdgcn_sched_group_barrier(0x200, PA + PB, 0);                                  \
             __builtin_amdgcn_sched_group_barrier(0x008, 4 * WM * WN, 0);                                        \
         }                                                                                                       \
-        if (MORE) __builtin_amdgcn_sched_group_barrier(0x200, PA + PB, 0);                                      \
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * WM * WN, 0);                                            \
         __syncthreads();                                                                                        \
         buf ^= 1;                                                                                               \
+        if (LOAD) GDPSO_GADVANCE()                                                                              \
     }
     int buf = 0;
     if constexpr (PF2) {
@@ -528,6 +573,10 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
         if (nk > 0) GDPSO_KSTEP(false, 0, false, 0)
     }
 #undef GDPSO_KSTEP
+#undef GDPSO_SGB
+#undef GDPSO_GISSUE
+#undef GDPSO_GADVANCE
+#undef GDPSO_DBG
 #undef GDPSO_SET_TAP
 #undef GDPSO_GLOAD
 #undef GDPSO_SSTORE
@@ -1008,6 +1057,10 @@ extern "C" int gdpso_conv_timing_end(double *total_ms, int *launches, double *fl
 #ifdef GDPSO_STAMPS
 extern "C" int gdpso_conv_stamps_set(void *device_buffer) {
     GDPSO_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gdpso::g_stamps), &device_buffer, sizeof(void *)));
+    return GDPSO_OK;
+}
+extern "C" int gdpso_conv_debug_skip(int bits) {
+    GDPSO_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gdpso::g_dbg_skip), &bits, sizeof(int)));
     return GDPSO_OK;
 }
 #endif

@@ -39,6 +39,8 @@ def main():
     lib.gdpso_conv_stamps_set.argtypes = [C.c_void_p]
     buf = torch.zeros(1 << 16, 16, dtype=torch.int64, device="cuda")
     assert lib.gdpso_conv_stamps_set(buf.data_ptr()) == 0, lib.gdpso_last_error()
+    if os.environ.get("GDPSO_DEBUG_SKIP"):  # 1: no MFMAs, 2: no global loads, 4: no LDS stores in the K loop (sum them)
+        assert lib.gdpso_conv_debug_skip(int(os.environ["GDPSO_DEBUG_SKIP"])) == 0
     us, tile, splits = C.c_double(), C.c_int(), C.c_int()
     rc = lib.gdpso_conv_probe(*a, 5, C.byref(us), C.byref(tile), C.byref(splits))
     assert rc == 0, lib.gdpso_last_error()
