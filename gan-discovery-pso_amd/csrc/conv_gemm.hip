@@ -502,6 +502,8 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
     // MFMAs of a K-step simply added up.
 #define GDPSO_SGB(MASK, N) \
     if ((N) > 0) __builtin_amdgcn_sched_group_barrier(MASK, (N) > 0 ? (N) : 1, 0);
+#define GDPSO_SGB4(MA, NA, MB, NB) \
+    GDPSO_SGB(MA, NA) GDPSO_SGB(MB, NB) GDPSO_SGB(MA, NA) GDPSO_SGB(MB, NB) GDPSO_SGB(MA, NA) GDPSO_SGB(MB, NB) GDPSO_SGB(MA, NA) GDPSO_SGB(MB, NB)
 #define GDPSO_KSTEP(LOAD, LS, MORE, SS)                                                                         \
     {                                                                                                           \
         if ((LOAD) && GDPSO_DBG(2)) GDPSO_GISSUE(LS)                                                            \
@@ -536,13 +538,16 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
             GDPSO_SGB(0x008, 1) GDPSO_SGB(0x200, NW / 4)                                                        \
             GDPSO_SGB(0x008, 3)                                                                                 \
         } else {                                                                                                \
-            __builtin_amdgcn_sched_group_barrier(0x100, WM + WN, 0);                                            \
-            _Pragma("unroll") for (int g = 0; g < 3; ++g) {                                                     \
-                __builtin_amdgcn_sched_group_barrier(0x100, WM + WN, 0);                                        \
-                __builtin_amdgcn_sched_group_barrier(0x008, 4 * WM * WN, 0);                                    \
-            }                                                                                                   \
-            if (MORE) __builtin_amdgcn_sched_group_barrier(0x200, PA + PB, 0);                                  \
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * WM * WN, 0);                                        \
+            /* 2 x 2 blocks: 64 MFMAs in pairs; per group of 16: the next group's four fragment reads    */    \
+            /* behind the first four pairs, then a load (groups 0, 1) or two LDS stores (groups 2, 3)     */    \
+            /* behind each of the other four                                                              */    \
+            static_assert(WM == 2 && WN == 2 && PA + PB == 8, "pinned for the 128x128 tile");                   \
+            constexpr int NV = (LOAD) ? 1 : 0, NW = (MORE) ? 1 : 0;                                             \
+            GDPSO_SGB(0x100, 4)                                                                                 \
+            GDPSO_SGB4(0x008, 2, 0x100, 1) GDPSO_SGB4(0x008, 2, 0x020, NV)                                      \
+            GDPSO_SGB4(0x008, 2, 0x100, 1) GDPSO_SGB4(0x008, 2, 0x020, NV)                                      \
+            GDPSO_SGB4(0x008, 2, 0x100, 1) GDPSO_SGB4(0x008, 2, 0x200, NW)                                      \
+            GDPSO_SGB4(0x008, 2, 0x200, NW) GDPSO_SGB(0x008, 8)                                                 \
         }                                                                                                       \
         __syncthreads();                                                                                        \
         buf ^= 1;                                                                                               \
@@ -574,6 +579,7 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
     }
 #undef GDPSO_KSTEP
 #undef GDPSO_SGB
+#undef GDPSO_SGB4
 #undef GDPSO_GISSUE
 #undef GDPSO_GADVANCE
 #undef GDPSO_DBG
