@@ -105,9 +105,7 @@ __device__ __attribute__((aligned(128))) float g_zero_page[MAX_CIN + 32] = {};
 #ifdef GDPSO_STAMPS
 // Diagnostic build only (tools/stamp_probe.py): per-workgroup time stamps of the tile code.
 __device__ unsigned long long *g_stamps = nullptr;
-// bit 0: skip the MFMAs of the K loop, bit 1: skip its global loads, bit 2: skip its LDS stores
-// (what is left shows what the skipped part costs; results are garbage)
-__device__ int g_dbg_skip = 0;
+
 #define GDPSO_STAMP(SLOT)                                                                   \
     if (g_stamps && threadIdx.x == 0) {                                                     \
         g_stamps[(size_t)blockIdx.x * 16 + (SLOT)] = __builtin_amdgcn_s_memtime();           \
@@ -487,9 +485,11 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
     // registers to the other LDS buffer ahead of the last group, in the shadow of the MFMAs that
     // are still executing, instead of after them.  The sched_group_barrier sequence pins that
     // order (0x100 = DS read, 0x200 = DS write, 0x008 = MFMA).
-#ifdef GDPSO_STAMPS
-    const int dbg_skip = g_dbg_skip;
-#define GDPSO_DBG(BIT) (!(dbg_skip & (BIT)))
+    // Diagnostic builds may compile parts of the K loop out (-DGDPSO_SKIP_BITS=n; bit 0: its MFMAs,
+    // bit 1: its global loads, bit 2: its LDS stores): what is left shows what the skipped part
+    // costs; results are garbage.
+#ifdef GDPSO_SKIP_BITS
+#define GDPSO_DBG(BIT) (!((GDPSO_SKIP_BITS) & (BIT)))
 #else
 #define GDPSO_DBG(BIT) true
 #endif
@@ -1065,10 +1065,7 @@ extern "C" int gdpso_conv_stamps_set(void *device_buffer) {
     GDPSO_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gdpso::g_stamps), &device_buffer, sizeof(void *)));
     return GDPSO_OK;
 }
-extern "C" int gdpso_conv_debug_skip(int bits) {
-    GDPSO_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gdpso::g_dbg_skip), &bits, sizeof(int)));
-    return GDPSO_OK;
-}
+
 #endif
 
 extern "C" double gdpso_conv_timing_bytes(void) { return gdpso::g_timing.bytes; }

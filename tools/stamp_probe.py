@@ -2,6 +2,7 @@
 """Where a convolution launch spends its time, from in-kernel time stamps (diagnostic build).
 
     python tools/stamp_probe.py build                      # here (needs hipcc): builds tools/libgdpso_stamps.so
+                                                           # (GDPSO_SKIP_BITS=n in the environment compiles parts of the K loop out)
     python tools/stamp_probe.py n hin cin cout k stride pad tile splits res    # on the GPU
 
 Every workgroup stamps s_memtime at entry, after its prologue (first K-tile in LDS), after its
@@ -23,6 +24,8 @@ def build():
     srcs = ["pack.cpp", "conv_gemm.hip", "nets.hip", "pso.hip", "vq.hip"]
     cmd = (["/opt/rocm/bin/hipcc", "-shared", "-o", LIB, "-x", "hip"] + [os.path.join(CSRC, s) for s in srcs] +
            ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-DGDPSO_STAMPS"])
+    if os.environ.get("GDPSO_SKIP_BITS"):  # 1: no MFMAs, 2: no global loads, 4: no LDS stores in the K loop (sum them)
+        cmd.append("-DGDPSO_SKIP_BITS=" + os.environ["GDPSO_SKIP_BITS"])
     print(" ".join(cmd))
     subprocess.check_call(cmd)
 
@@ -39,8 +42,6 @@ def main():
     lib.gdpso_conv_stamps_set.argtypes = [C.c_void_p]
     buf = torch.zeros(1 << 16, 16, dtype=torch.int64, device="cuda")
     assert lib.gdpso_conv_stamps_set(buf.data_ptr()) == 0, lib.gdpso_last_error()
-    if os.environ.get("GDPSO_DEBUG_SKIP"):  # 1: no MFMAs, 2: no global loads, 4: no LDS stores in the K loop (sum them)
-        assert lib.gdpso_conv_debug_skip(int(os.environ["GDPSO_DEBUG_SKIP"])) == 0
     us, tile, splits = C.c_double(), C.c_int(), C.c_int()
     rc = lib.gdpso_conv_probe(*a, 5, C.byref(us), C.byref(tile), C.byref(splits))
     assert rc == 0, lib.gdpso_last_error()
