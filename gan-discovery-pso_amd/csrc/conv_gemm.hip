@@ -119,11 +119,12 @@ __device__ unsigned long long *g_stamps = nullptr;
 #define GDPSO_STAMP(SLOT)
 #endif
 
-__device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == ACT_RELU) return v > 0.f ? v : 0.f;
-    if (act == ACT_LEAKY02) return v > 0.f ? v : 0.2f * v;
-    return v;
-}
+// Activations as one branch-free formula, max(v, 0) + slope * min(v, 0) with slope 1 (none), 0 (ReLU)
+// or 0.2 (LeakyReLU): the same values as the three definitions (one of the two terms is always a
+// zero), and the store passes need no branch on a run-time activation code per pass.
+__device__ __forceinline__ float act_slope(int act) { return act == ACT_RELU ? 0.f : (act == ACT_LEAKY02 ? 0.2f : 1.f); }
+__device__ __forceinline__ float apply_slope(float v, float slope) { return fmaxf(v, 0.f) + slope * fminf(v, 0.f); }
+__device__ __forceinline__ float apply_act(float v, int act) { return apply_slope(v, act_slope(act)); }
 
 // What a thread needs for its part of the store pass, gathered BEFORE the accumulators go to
 // LDS: the loads of scale, shift and (unsplit layers) the residual are then in flight across the
@@ -201,7 +202,7 @@ __device__ __forceinline__ void conv_store_tile(const ConvKArgs &a, float *lds, 
             f32x4 v = tile_quad(pass * RPP + r0);
             v = v * sc + sh;
             if constexpr (Plan::PREFETCH_RES) {
-                if (a.res) v += plan.rres[pass];
+                v += plan.rres[pass];  // zeros without a residual
             } else {
                 if (a.res) v += *(const f32x4 *)(a.res + off[pass]);
             }
@@ -628,9 +629,11 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
             }
             f32x4 rres[4];
 #pragma unroll
-            for (int pass = 0; pass < 4; ++pass) {
-                rres[pass] = 0.f;
-                if (f.res && off[pass] >= 0) rres[pass] = *(global_f32x4_ptr)(f.res + off[pass] + cb * 64);
+            for (int pass = 0; pass < 4; ++pass) rres[pass] = 0.f;
+            if (f.res) {  // straight-line: rows past M read the first row's residual, which is not used
+#pragma unroll
+                for (int pass = 0; pass < 4; ++pass)
+                    rres[pass] = *(global_f32x4_ptr)(f.res + (off[pass] < 0 ? c4 * 4 : off[pass]) + cb * 64);
             }
             __syncthreads();
             f32x16 acc2;
