@@ -273,3 +273,8 @@ int gdpso_abi_version(void) { return GDPSO_ABI_VERSION; }
 const char *gdpso_last_error(void) { return gdpso::last_error_cstr(); }
 size_t gdpso_struct_size(int which) { return which == 0 ? sizeof(gdpso_swarm) : which == 1 ? sizeof(gdpso_run) : 0; }
 }
+
+extern "C" unsigned gdpso_fast_div_check(unsigned n, unsigned d) {
+    const gdpso::FastDiv f = gdpso::fast_div_for(d);
+    return (unsigned)(((unsigned long long)n * f.mul) >> f.shift);
+}

@@ -273,6 +273,11 @@ double gdpso_conv_timing_executed_flops(void);
 int gdpso_conv_plan_describe(int n_images, int hin, int cin, int cout, int ksize, int stride, int pad, int transposed,
                              int num_cus, int *out, int max_ints);
 
+/* No counterpart in the reference: n / d the way the kernels compute it (multiply by a host-made
+ * constant, shift; the chip has no integer divide), on the host, so that a test can compare it
+ * with the exact quotient.  0 <= n < 2^31, d >= 1. */
+unsigned gdpso_fast_div_check(unsigned n, unsigned d);
+
 /* No counterpart in the reference: times one ksize x ksize convolution layer in isolation
  * on random data (allocates and frees its own buffers; a development / tuning aid).
  * tile (0 = planner's choice; 128 = 128x128, 64 = 64x64, 32 = 32x64 with the K-tile split over two wave

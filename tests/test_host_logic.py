@@ -182,3 +182,22 @@ def test_conv_plan_shapes(pkg):
     assert p["tile"] == 16 and p["splits"] == 4
     assert _describe(lib, 8192, 7, 256, 256, 1, 1, 0)["tile"] == 128      # deep grid: 128x128
     assert _describe(lib, 1, 7, 64, 64, 3, 1, 1)["splits"] >= 1
+
+
+def test_multiply_shift_division_is_exact():
+    """The kernels divide row and tile indices by run-time constants with a multiply and a shift
+    (constants made on the host by fast_div_for); the same arithmetic on the host against the
+    exact quotient: every divisor up to 4096 and a spread of large ones, dividends at every
+    multiple's edges, at random and at the top of the range."""
+    f = imp("_lib").lib().gdpso_fast_div_check
+    rng = np.random.default_rng(5)
+    top = 2 ** 31 - 1
+    divisors = list(range(1, 4097)) + [int(x) for x in rng.integers(4097, 2 ** 24, 300)] + [2 ** 24, 2 ** 30, top]
+    for d in divisors:
+        ns = {0, 1, d - 1, d, d + 1, top, top - 1, (top // d) * d, max(0, (top // d) * d - 1)}
+        ns.update(int(x) for x in rng.integers(0, top, 6))
+        for k in rng.integers(1, max(2, top // d), 4):
+            ns.update((int(k) * d - 1, int(k) * d))
+        for n in ns:
+            if 0 <= n <= top:
+                assert f(n, d) == n // d, (n, d)
