@@ -166,6 +166,7 @@ def main():
     dbg("warm-up done")
     t0 = time.perf_counter()
     run(w + 1, k)
+    t_enqueued = time.perf_counter() - t0  # host time to enqueue the K steps (the device runs behind it)
     fence()
     dt = time.perf_counter() - t0
     if comm is not None:
@@ -228,6 +229,7 @@ def main():
                                    f"{n_global} particles total", "particles_per_gpu": p, "z_dim": z_dim,
                        "flop_per_particle_eval": flop_per_eval, "parallelism": f"particle shards x{world}"},
             "end_to_end_tflops": round(value * flop_per_eval / 1e12, 3),
+            "host_enqueue_ms_per_step": round(1e3 * t_enqueued / k, 4),
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
