@@ -37,7 +37,7 @@ def main():
                 tot[1] += a[k][1]
         a["conv_gemm (all instantiations)"] = tot
     for k in fe:
-        if fe[k][1] < 1000:
+        if fe[k][1] <= 0 or not (k.startswith("gdpso::") or k.startswith("conv_gemm")):
             continue
         c, v = fe[k]
         cw, vw = wr.get(k, [c, 0.0])
