@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--particles", type=int, default=512, help="particles per GPU")
     ap.add_argument("--z-dim", type=int, default=10)
+    ap.add_argument("--side", type=int, default=28, help="image side (28: DCGAN-MNIST; 64: the CLARO-sized generator)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -111,7 +112,7 @@ def main():
         comm = eng.TorchComm()
 
     z_dim, n_class, class_index = args.z_dim, 8, 6
-    gen = eng.PackedGenerator(synth.generator_state(z_dim, 1, 64, seed=11), dev)
+    gen = eng.PackedGenerator(synth.generator_state(z_dim, 1, 64, seed=11, first_kernel=args.side // 4), dev)
     ass = eng.PackedAssessor(synth.resnet_state("ResNet50", 1, n_class, seed=12), dev, img_side=gen.side)
     ev = eng.Evaluator(gen, ass)
     spec = eng.FitnessSpec(class_index=class_index)
@@ -200,7 +201,7 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")) as f:
                 pm = json.load(f)
-            if p == 512 and z_dim == 10:
+            if p == 512 and z_dim == 10 and args.side == 28:
                 traffic = pm["kernels"]["conv_gemm (all instantiations)"]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
@@ -225,7 +226,7 @@ def main():
             "metric": "particle-evaluations/sec (swarm x gen-fwd) DCGAN-MNIST", "value": round(value, 1),
             "unit": "particle-evals/s", "n_gpus": world, "steps": k, "warmup": w, "ms_per_step": round(1e3 * dt / k, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"DCGAN-MNIST 28x28, {p} particles per GPU, ResNet50 assessor (n_class=8), z_dim={z_dim}, "
+            "config": {"workload": f"DCGAN-MNIST {gen.side}x{gen.side}, {p} particles per GPU, ResNet50 assessor (n_class=8), z_dim={z_dim}, "
                                    f"{n_global} particles total", "particles_per_gpu": p, "z_dim": z_dim,
                        "flop_per_particle_eval": flop_per_eval, "parallelism": f"particle shards x{world}"},
             "end_to_end_tflops": round(value * flop_per_eval / 1e12, 3),
