@@ -196,19 +196,25 @@ __device__ __forceinline__ void conv_store_tile(const ConvKArgs &a, float *lds, 
     const f32x4 sc = plan.sc, sh = plan.sh;
     const int(&off)[PASSES] = plan.off;
     if (direct) {
+        const float slope = act_slope(a.act);
 #pragma unroll
         for (int pass = 0; pass < PASSES; ++pass) {
-            if (off[pass] < 0) continue;
-            f32x4 v = tile_quad(pass * RPP + r0);
-            v = v * sc + sh;
             if constexpr (Plan::PREFETCH_RES) {
-                v += plan.rres[pass];  // zeros without a residual
-            } else {
-                if (a.res) v += *(const f32x4 *)(a.res + off[pass]);
-            }
+                // every row computed, only the store masked: no branch ahead of the LDS read
+                f32x4 v = tile_quad(pass * RPP + r0);
+                v = v * sc + sh + plan.rres[pass];  // zeros without a residual
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = apply_act(v[q], a.act);
-            *(f32x4 *)(a.out + off[pass]) = v;
+                for (int q = 0; q < 4; ++q) v[q] = apply_slope(v[q], slope);
+                if (off[pass] >= 0) *(f32x4 *)(a.out + off[pass]) = v;
+            } else {
+                if (off[pass] < 0) continue;
+                f32x4 v = tile_quad(pass * RPP + r0);
+                v = v * sc + sh;
+                if (a.res) v += *(const f32x4 *)(a.res + off[pass]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = apply_slope(v[q], slope);
+                *(f32x4 *)(a.out + off[pass]) = v;
+            }
         }
         return;
     }
