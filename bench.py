@@ -62,6 +62,58 @@ def cpu_baseline(z_dim, n_class, class_index, seconds_budget=20.0):
             "sample": f"{n} particles x {iters} iterations, one particle per forward pass (reference-style loop), torch CPU fp32"}
 
 
+def launch_ranks(n_ranks, argv):
+    """`python bench.py --gpus N` without a launcher: run the same command line under
+    torch.distributed.run (one child process per GPU, rendezvous on 127.0.0.1 at a free port) and
+    print the one JSON line rank 0 writes.  Returns the exit code of the launch."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    lines = [ln for ln in proc.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    elif proc.returncode == 0:
+        print("bench.py: the ranks finished without a result line", file=sys.stderr)
+        return 1
+    return proc.returncode
+
+
+def dry_run(args, world, rank, result_fd):
+    """GDPSO_BENCH_DRYRUN=1: everything around the measurement without a GPU (rendezvous of the
+    ranks over gloo, one exchange of candidate records and positions through engine.TorchComm, the
+    max-over-ranks reduction, rank 0's result line), so that the launch path of `--gpus N` can be
+    tested where there is no GPU.  The line says "dry_run": true and carries no value."""
+    import torch.distributed as dist
+    eng = importlib.import_module("gan-discovery-pso_amd.engine")
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+        comm = eng.TorchComm()
+        d, p = args.z_dim, 4
+        cand = torch.zeros(world, d + 2, dtype=torch.float64)
+        cand[rank, 0], cand[rank, 1] = 1.0 + rank, rank * p
+        pos = torch.full((p, d), float(rank), dtype=torch.float64)
+        allp = comm.all_gather_step(cand, cand[rank], pos, world * p)
+        assert cand[:, 1].tolist() == [float(r * p) for r in range(world)]
+        assert allp[:, 0].tolist() == [float(r) for r in range(world) for _ in range(p)]
+        t = torch.tensor([float(rank)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert t.item() == world - 1
+        dist.barrier()
+    if rank == 0:
+        out = {"metric": "particle-evaluations/sec (swarm x gen-fwd) DCGAN-MNIST", "value": None, "unit": "particle-evals/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True}
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,6 +124,11 @@ def main():
     ap.add_argument("--side", type=int, default=28, help="image side (28: DCGAN-MNIST; 64: the CLARO-sized generator)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Started directly (python bench.py --gpus N): this process has not touched the GPU and never
+        # will; it starts one fresh rank per GPU and relays rank 0's result line.
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     # Libraries write to stdout too (RCCL prints a version banner there when a process group comes
     # up): everything but the result line goes to stderr.
@@ -84,6 +141,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if os.environ.get("GDPSO_BENCH_DRYRUN") == "1":
+        return dry_run(args, world, rank, result_fd)
     # GDPSO_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the multi-rank path
     backend = os.environ.get("GDPSO_BENCH_BACKEND", "nccl")
     local_rank %= max(1, torch.cuda.device_count()) if backend != "nccl" else 1 << 30

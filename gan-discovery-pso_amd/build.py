@@ -19,12 +19,25 @@ def _stale(target: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _flags_changed(stamp: str, key: str) -> bool:
+    """True when the objects on disk were built with other flags (or another compiler) than `key`."""
+    try:
+        with open(stamp) as f:
+            return f.read() != key
+    except OSError:
+        return True
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "gdpso.h")]
     objs = []
     procs = []
     os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
+    stamp = os.path.join(CSRC, "build", "flags.txt")
+    key = " ".join([hipcc] + FLAGS)
+    if _flags_changed(stamp, key):
+        force = True
     for src in SOURCES:
         obj = os.path.join(CSRC, "build", os.path.splitext(src)[0] + ".o")
         objs.append(obj)
@@ -42,6 +55,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    with open(stamp, "w") as f:
+        f.write(key)
     return LIB
 
 

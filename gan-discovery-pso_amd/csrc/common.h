@@ -109,6 +109,12 @@ void fold_bn(int c, const float *bias, const float *gamma, const float *beta, co
 void make_conv(ConvLayer &L, const float *w, int cout, int cin, int kh, int kw, int stride, int pad,
                int hin, int win, int act, std::vector<float> &packed, int cin_pad = 0, int cout_pad = 0);
 
+// Whether a kh x kw window with this padding fits a ConvPhase: at most MAX_TAPS taps per phase, tap
+// offsets (k - pad) representable in the int8 dy / dx fields.  make_conv does not check it.
+inline bool conv_window_fits(int ksize, int pad) {
+    return ksize >= 1 && (long)ksize * ksize <= MAX_TAPS && pad >= 0 && pad <= 127 && ksize - 1 - pad <= 127;
+}
+
 // Builds the 4-phase form of ConvTranspose2d(k4, s2, p1) from a PyTorch [cin][cout][4][4] weight.
 void make_convt_k4s2p1(ConvLayer &L, const float *w, int cin, int cout, int hin, int win, int act,
                        std::vector<float> &packed);

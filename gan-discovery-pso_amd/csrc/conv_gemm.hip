@@ -1091,6 +1091,10 @@ extern "C" int gdpso_conv_plan_describe(int n_images, int hin, int cin, int cout
         set_error("conv_plan_describe: bad window");
         return -GDPSO_ERR_ARG;
     }
+    if (!transposed && !conv_window_fits(ksize, pad)) {
+        set_error("conv_plan_describe: window too large (at most 64 taps, offsets within +-127)");
+        return -GDPSO_ERR_ARG;
+    }
     ConvLayer L;
     std::vector<float> packed;
     if (transposed) {
@@ -1126,6 +1130,8 @@ extern "C" int gdpso_conv_probe(int n_images, int hin, int cin, int cout, int ks
                                 int splits, int with_res, int reps, double *avg_us, int *tile_used, int *splits_used) {
     using namespace gdpso;
     GDPSO_REQUIRE(n_images > 0 && hin > 0 && cin % 32 == 0 && cout % 64 == 0 && reps > 0 && avg_us, "conv_probe: bad argument");
+    GDPSO_REQUIRE(ksize > 0 && stride > 0 && pad >= 0 && hin + 2 * pad >= ksize && conv_window_fits(ksize, pad),
+                  "conv_probe: bad window (at most 64 taps, offsets within +-127)");
     GDPSO_REQUIRE(tile == 0 || tile == 64 || (tile == 32 && cin % 64 == 0) || (tile == TILE_32x32 && cin % 128 == 0) ||
                       (tile == 128 && cout % 128 == 0),
                   "conv_probe: bad tile");
@@ -1193,6 +1199,7 @@ extern "C" int gdpso_conv_layer_run(int n_images, int hin, int cin, int cout, in
     GDPSO_REQUIRE(weight && scale && shift && in && out, "conv_layer_run: null pointer");
     GDPSO_REQUIRE(act == ACT_NONE || act == ACT_RELU || act == ACT_LEAKY02, "conv_layer_run: bad activation");
     GDPSO_REQUIRE(transposed || (ksize > 0 && stride > 0 && pad >= 0 && hin + 2 * pad >= ksize), "conv_layer_run: bad window");
+    GDPSO_REQUIRE(transposed || conv_window_fits(ksize, pad), "conv_layer_run: window too large (at most 64 taps, offsets within +-127)");
     GDPSO_REQUIRE(tile == 0 || tile == 64 || (tile == 32 && cin % 64 == 0) || (tile == TILE_32x32 && cin % 128 == 0) ||
                       (tile == 128 && cout % 128 == 0),
                   "conv_layer_run: bad tile");

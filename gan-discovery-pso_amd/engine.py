@@ -14,6 +14,7 @@ PyTorch is used for device memory, streams and ``torch.distributed`` only.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -280,8 +281,12 @@ class Evaluator:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
+    MAX_IMAGE_BUFFER_SETS = 4  # distinct batch sizes whose image buffers are kept
+
     def image_buffers(self, n):
         if n not in self._img:
+            while len(self._img) >= self.MAX_IMAGE_BUFFER_SETS:  # drop the set that was created first
+                self._img.pop(next(iter(self._img)))
             s = self.gen.side
             self._img[n] = (torch.empty(n, s, s, dtype=torch.float32, device=self.device),
                             torch.empty(n, s, s, dtype=torch.float32, device=self.device),
@@ -526,6 +531,9 @@ class TorchComm:
         # several ranks on one GPU) device tensors are staged through the host explicitly.  RCCL
         # collectives run in stream order on the device tensors themselves.
         self.host_staged = dist.get_backend(group) == "gloo"
+        # GDPSO_COMM_COALESCE=0 keeps every exchange as two plain all-gathers
+        self.can_coalesce = os.environ.get("GDPSO_COMM_COALESCE", "1") != "0"
+        self.coalesced_steps = 0  # exchanges that went out as one coalesced launch
 
     def _all_gather_flat(self, out_flat: torch.Tensor, inp_flat: torch.Tensor):
         if self.host_staged and out_flat.is_cuda:
@@ -558,18 +566,26 @@ class TorchComm:
         return n_max, self._pos_all
 
     def all_gather_step(self, cand_out: torch.Tensor, cand_row: torch.Tensor, pos: torch.Tensor, n_global: int) -> torch.Tensor:
-        """The candidate table AND every rank's positions in one exchange: with RCCL and equal
-        shards the two all-gathers are coalesced into one launch; otherwise they run one after
-        the other.  Returns the positions like gather_positions."""
+        """The candidate table AND every rank's positions in one exchange: with equal shards the two
+        all-gathers are coalesced into one launch (torch.distributed's coalescing manager, where this
+        torch build has it and the backend accepts it); otherwise they run one after the other, which
+        gives the same tensors.  Returns the positions like gather_positions."""
         n_max, allp = self._pos_buffers(pos, n_global)
-        if self.host_staged or n_global != self.world * n_max or not hasattr(self.dist, "_coalescing_manager"):
-            self.all_gather(cand_out, cand_row)
-            return self.gather_positions(pos, n_global)
-        rec = self._rec_copy(cand_row)
-        with self.dist._coalescing_manager(group=self.group):
-            self.dist.all_gather_into_tensor(cand_out.view(-1), rec.view(-1), group=self.group)
-            self.dist.all_gather_into_tensor(allp.view(-1), pos.reshape(-1), group=self.group)
-        return allp
+        staged = self.host_staged and pos.is_cuda
+        if not (staged or n_global != self.world * n_max or not self.can_coalesce):
+            rec = self._rec_copy(cand_row)
+            try:
+                with self.dist._coalescing_manager(group=self.group):
+                    self.dist.all_gather_into_tensor(cand_out.view(-1), rec.view(-1), group=self.group)
+                    self.dist.all_gather_into_tensor(allp.view(-1), pos.reshape(-1), group=self.group)
+                self.coalesced_steps += 1
+                return allp
+            except (AttributeError, NotImplementedError, TypeError, RuntimeError):
+                # no coalescing in this torch build / backend: from now on the plain form (the
+                # failed attempt wrote nothing that the two calls below do not overwrite)
+                self.can_coalesce = False
+        self.all_gather(cand_out, cand_row)
+        return self.gather_positions(pos, n_global)
 
     def gather_positions(self, pos: torch.Tensor, n_global: int) -> torch.Tensor:
         """Every rank's positions, in global particle order.  The returned tensor is a buffer of

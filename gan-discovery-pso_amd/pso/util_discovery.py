@@ -26,13 +26,32 @@ class Discovery:
             self.class_to_idx = {c: i for i, c in enumerate(sorted(iid_classes))}
             self.idx_to_class = {i: c for c, i in self.class_to_idx.items()}
         self._evaluator = None
+        self._evaluator_key = None
 
     # ---- device objects
+    @staticmethod
+    def _model_key(model):
+        """Changes whenever a weight of ``model`` is replaced or written in place (load_state_dict,
+        .to(), optimiser steps): storage address and version counter of every tensor; numpy arrays
+        (plain dicts of arrays are accepted as models) by address."""
+        sd = model if isinstance(model, dict) else model.state_dict(keep_vars=True)
+        key = []
+        for v in sd.values():
+            if isinstance(v, torch.Tensor):
+                key.append((v.data_ptr(), v._version, str(v.device)))
+            else:
+                key.append((id(v),))
+        return tuple(key)
+
     def evaluator(self) -> engine.Evaluator:
-        if self._evaluator is None:
+        """The packed device copy of the two networks; rebuilt when either model's weights have
+        changed since it was packed (the reference calls the live modules every time)."""
+        key = (self._model_key(self.model_gan), self._model_key(self.model_cnn), str(self.device))
+        if self._evaluator is None or self._evaluator_key != key:
             gen = engine.PackedGenerator(self.model_gan, self.device)
             ass = engine.PackedAssessor(self.model_cnn, self.device, img_side=gen.side)
             self._evaluator = engine.Evaluator(gen, ass)
+            self._evaluator_key = key
         return self._evaluator
 
     def fitness_spec(self, eps=0.1, w_ass=1.0, w_rec=1.0) -> engine.FitnessSpec:

@@ -99,7 +99,8 @@ def main():
                  tolerance=1e-5, diagnostics=True, comm=comm)
     hist = comm.gather_rows(np.stack(sw.hist), 1, n)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), hist=hist, dummy=np.array(sw.dummy, np.float32),
-             g_best_val=np.array(sw.g_best_val, np.float32), gbest_pos=sw.gbest_pos, mean_mse=np.array(sw.mean_mse))
+             g_best_val=np.array(sw.g_best_val, np.float32), gbest_pos=sw.gbest_pos, mean_mse=np.array(sw.mean_mse),
+             coalesced_steps=np.array(comm.coalesced_steps))
     dist.destroy_process_group()
 
 

@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from conftest import load_golden
+from parity_utils import first_ambiguous_iteration
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -94,3 +95,58 @@ def test_deep_assessors_against_oracle(eng, oracle, synth, model):
     z = np.random.RandomState(8).standard_normal((11, 10))
     got, _, _ = ev.fitness(torch.from_numpy(z).cuda(), eng.FitnessSpec(class_index=2))
     np.testing.assert_allclose(got.cpu().numpy(), fit(z), atol=TOL)
+
+
+# The 64x64 generator (first ConvTranspose kernel 16: 16 -> 32 -> 64) is this build's extension of the
+# reference generator, which is hard-wired to 7 -> 14 -> 28 (reference src/utils/util_dcgan.py:135-137).
+# PARITY UNPINNED BY THE REFERENCE: there is no reference output for it; it is checked against the
+# oracle's restatement of the same three layers, which reads the first kernel size off the weights.
+@pytest.fixture(scope="module")
+def nets64(eng, synth):
+    dev = torch.device("cuda:0")
+    gstate = synth.generator_state(10, 1, 64, seed=11, first_kernel=16)
+    cstate = synth.resnet_state("ResNet50", 1, 8, seed=12)
+    ev = eng.Evaluator(eng.PackedGenerator(gstate, dev), eng.PackedAssessor(cstate, dev, img_side=64))
+    return ev, synth.to_torch(gstate), synth.to_torch(cstate)
+
+
+@pytest.mark.parametrize("n", [1, 5, 64])
+def test_generator_64x64_against_oracle(eng, oracle, nets64, n):
+    """Images, rescaled images and fitness of the 64x64 configuration (the last generator layer
+    takes its unstaged VALU form here: neither the staged image nor the MFMA form fits LDS)."""
+    ev, gsd, csd = nets64
+    assert ev.gen.side == 64
+    z = np.random.RandomState(40 + n).standard_normal((n, 10))
+    img01, img, _ = ev.images(torch.from_numpy(z).cuda())
+    with torch.no_grad():
+        want = oracle.generator_forward(gsd, torch.from_numpy(z).float().reshape(n, 10, 1, 1))
+        want01 = oracle.rescale_per_image(want)
+    np.testing.assert_allclose(img.cpu().numpy(), want[:, 0].numpy(), atol=TOL)
+    np.testing.assert_allclose(img01.cpu().numpy(), want01[:, 0].numpy(), atol=TOL)
+    fit = oracle.Fitness(gsd, csd, 6)
+    got, _, _ = ev.fitness(torch.from_numpy(z).cuda(), eng.FitnessSpec(class_index=6))
+    np.testing.assert_allclose(got.cpu().numpy(), fit(z), atol=TOL)
+
+
+def test_swarm_64x64_against_oracle(eng, oracle, nets64):
+    """A short swarm at 64x64 (16 particles, 5 iterations) against the oracle's loop on the same
+    draws: per-iteration fitness within 1e-4 and, while the decisions agree, identical positions."""
+    ev, gsd, csd = nets64
+    n, t, d = 16, 5, 10
+    rs = np.random.RandomState(77)
+    pos, vel = oracle.init_swarm(n, d, rs)
+    rand = rs.random_sample((t, n, 2))
+    ref = oracle.run_swarm(oracle.Fitness(gsd, csd, 6), pos, vel, t, 0.73, 1.496, 1.496, early_stopping=False, rand=rand, batch=n)
+    sw = eng.HipSwarm(ev, n, d, t, record_fitness=True)
+    sw.load(pos, vel, 0.73, rand=rand)
+    eng.run_loop(sw, t, eng.FitnessSpec(class_index=6), 1.496, 1.496, early_stopping=False, tolerance=1e-4)
+    res = sw.results()
+    assert res["iters"] == t
+    # decisions are strict compares on fp32 fitness: the trajectories are compared while every
+    # compare of the oracle's run has a margin above the fp32 noise of the fitness
+    safe = first_ambiguous_iteration(np.stack(ref["fitness"]), 2e-5)
+    assert safe >= 2, "choose another seed: the first iterations of this run are too close to call"
+    for i in range(safe):
+        np.testing.assert_allclose(res["fitness"][i], ref["fitness"][i], atol=TOL)
+    np.testing.assert_array_equal(res["hist_pos"][:safe + 1], np.stack(ref["pos"])[:safe + 1])
+    np.testing.assert_allclose(res["g_best_val_dummy"][:safe], np.array(ref["g_best_val_dummy"][:safe], np.float32), atol=TOL)

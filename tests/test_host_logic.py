@@ -1,10 +1,14 @@
 """Host-side logic that needs no GPU: state_dict layouts, weight extraction order,
 sharding arithmetic, fitness settings, loud failure off-GPU."""
 import importlib
+import os
+import sys
 
 import numpy as np
 import pytest
 import torch
+
+from conftest import ROOT
 
 imp = lambda n: importlib.import_module("gan-discovery-pso_amd." + n)
 
@@ -184,6 +188,19 @@ def test_conv_plan_shapes(pkg):
     assert _describe(lib, 1, 7, 64, 64, 3, 1, 1)["splits"] >= 1
 
 
+def test_conv_window_larger_than_the_tap_table_is_refused(pkg):
+    """A k x k window with more taps than a phase's table holds (64), or offsets beyond int8, is an
+    argument error at the C ABI, not a write past the table."""
+    import ctypes as C
+    L = imp("_lib").lib()
+    buf = (C.c_int * 8192)()
+    assert L.gdpso_conv_plan_describe(4, 16, 64, 64, 8, 1, 0, 0, 256, buf, 8192) > 0      # 64 taps: the most that fit
+    assert L.gdpso_conv_plan_describe(4, 16, 64, 64, 9, 1, 0, 0, 256, buf, 8192) < 0      # 81 taps
+    assert b"window too large" in L.gdpso_last_error()
+    assert L.gdpso_conv_plan_describe(4, 16, 64, 64, 3, 1, 200, 0, 256, buf, 8192) < 0    # offset -200
+    assert L.gdpso_conv_plan_describe(4, 16, 64, 64, 11, 1, 5, 0, 256, buf, 8192) < 0
+
+
 def test_multiply_shift_division_is_exact():
     """The kernels divide row and tile indices by run-time constants with a multiply and a shift
     (constants made on the host by fast_div_for); the same arithmetic on the host against the
@@ -201,3 +218,40 @@ def test_multiply_shift_division_is_exact():
         for n in ns:
             if 0 <= n <= top:
                 assert f(n, d) == n // d, (n, d)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2`, started directly as the round-end driver starts it, brings up two
+    ranks by itself and relays rank 0's one JSON line (dry run: rendezvous, one exchange through
+    engine.TorchComm and the max-over-ranks reduction over gloo, no GPU work)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(GDPSO_BENCH_DRYRUN="1", OMP_NUM_THREADS="1")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["dry_run"] is True and out["steps"] == 3
+
+
+def test_evaluator_cache_key_follows_the_weights(synth):
+    """Discovery re-packs its device copy when a model's weights change: the key it caches the packed
+    evaluator under moves on load_state_dict (in-place copy: version counters) and on a replaced
+    tensor (new storage), and stays put otherwise."""
+    Discovery = imp("pso.util_discovery").Discovery
+    gen = imp("utils.util_dcgan").Generator(10, 1, 64)
+    k0 = Discovery._model_key(gen)
+    assert Discovery._model_key(gen) == k0
+    gen.load_state_dict(synth.to_torch(synth.generator_state(10, 1, 64, seed=5)))
+    k1 = Discovery._model_key(gen)
+    assert k1 != k0
+    with torch.no_grad():
+        next(gen.parameters()).mul_(2.0)
+    assert Discovery._model_key(gen) != k1
+    sd = synth.generator_state(10, 1, 64, seed=5)
+    k2 = Discovery._model_key(sd)
+    sd[next(iter(sd))] = np.array(sd[next(iter(sd))])
+    assert Discovery._model_key(sd) != k2
