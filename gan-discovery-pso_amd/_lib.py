@@ -73,6 +73,7 @@ _PROTOTYPES = {
     "gdpso_vq_seed_codebook": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int]),
     "gdpso_vq_nearest": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
     "gdpso_vq_lookup": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "gdpso_vq_nearest_static": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gdpso_swarm_scratch_bytes": (c_size_t, [c_int]),
     "gdpso_swarm_reset": (c_int, [C.POINTER(SwarmDesc), c_void_p, c_double]),
     "gdpso_swarm_local_best": (c_int, [C.POINTER(SwarmDesc), c_void_p, c_int, c_int]),

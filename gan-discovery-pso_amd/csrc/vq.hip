@@ -13,6 +13,8 @@
 
 #include <math.h>
 
+#include <mutex>
+
 namespace gdpso {
 namespace {
 
@@ -167,6 +169,64 @@ extern "C" int gdpso_vq_nearest(void *stream_, int n, int d, int k, const float 
     hipStream_t stream = (hipStream_t)stream_;
     const int kp = round_up64(k);
     float *cbt = (float *)workspace, *csq = cbt + (size_t)d * kp;
+    hipLaunchKernelGGL(vq_prepare_kernel, dim3(cdiv(kp, 256)), dim3(256), 0, stream, codebook, k, d, kp, cbt, csq);
+    hipLaunchKernelGGL(vq_nearest_kernel, dim3(cdiv(n, VQ_ROWS)), dim3(VQ_THREADS), (size_t)VQ_ROWS * d * sizeof(float), stream,
+                       inputs, n, d, k, kp, cbt, csq, codebook, indices, codes, best_dist);
+    GDPSO_HIP(hipGetLastError());
+    return GDPSO_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// The same search for callers that cannot allocate (HIP graph capture, tight serving loops):
+// the transposed codebook and the squared norms go to a file-scope device array instead of a
+// caller workspace.  Every GPU the library runs on holds its own copy of the array (1 MiB) at
+// its own address until the process ends; in host code the array's NAME is not a device address,
+// so the address is asked for once per device (hipGetSymbolAddress, with that device current) and
+// only that pointer is handed to kernels.
+namespace gdpso {
+namespace {
+constexpr size_t VQ_STATIC_FLOATS = GDPSO_VQ_STATIC_MAX_BYTES / sizeof(float);  // (d + 1) * round_up64(k) floats at most
+static __device__ __align__(256) float scratch[VQ_STATIC_FLOATS];
+
+constexpr int VQ_MAX_DEVICES = 64;
+float *g_scratch_ptr[VQ_MAX_DEVICES] = {};
+std::mutex g_scratch_mutex;
+
+// Device address of `scratch` on the current device (looked up on the first call per device).
+int vq_static_scratch(float **out) {
+    int dev = -1;
+    GDPSO_HIP(hipGetDevice(&dev));
+    GDPSO_REQUIRE(dev >= 0 && dev < VQ_MAX_DEVICES, "vq_nearest_static: device ordinal above 63");
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void *p = nullptr;
+        GDPSO_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        GDPSO_REQUIRE(p != nullptr, "vq_nearest_static: no device address for the scratch array");
+        g_scratch_ptr[dev] = (float *)p;
+    }
+    *out = g_scratch_ptr[dev];
+    return GDPSO_OK;
+}
+}  // namespace
+}  // namespace gdpso
+
+extern "C" int gdpso_vq_nearest_static(void *stream_, int n, int d, int k, const float *inputs, const float *codebook,
+                                       long long *indices, float *codes, float *best_dist) {
+    GDPSO_REQUIRE(n >= 0 && k > 0 && d > 0, "vq_nearest_static: n >= 0, k > 0 and d > 0 are required");
+    GDPSO_REQUIRE(n == 0 || (inputs && codebook && indices), "vq_nearest_static: null argument");
+    GDPSO_REQUIRE(d <= VQ_MAX_D, "vq_nearest_static: embedding size above 4096");
+    if (gdpso_vq_workspace_bytes(k, d) > VQ_STATIC_FLOATS * sizeof(float))
+        return fail(GDPSO_ERR_WORKSPACE, "vq_nearest_static: (d + 1) * round_up(k, 64) floats exceed the 1 MiB static scratch; "
+                                         "use gdpso_vq_nearest with a caller workspace");
+    if (n == 0) return GDPSO_OK;
+    float *ws = nullptr;
+    int rc = vq_static_scratch(&ws);
+    if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int kp = round_up64(k);
+    // both kernels take the looked-up pointer; the prepare kernel rewrites every word the search
+    // reads (d * kp transposed codes, kp norms), so nothing of an earlier call's contents survives
+    float *cbt = ws, *csq = cbt + (size_t)d * kp;
     hipLaunchKernelGGL(vq_prepare_kernel, dim3(cdiv(kp, 256)), dim3(256), 0, stream, codebook, k, d, kp, cbt, csq);
     hipLaunchKernelGGL(vq_nearest_kernel, dim3(cdiv(n, VQ_ROWS)), dim3(VQ_THREADS), (size_t)VQ_ROWS * d * sizeof(float), stream,
                        inputs, n, d, k, kp, cbt, csq, codebook, indices, codes, best_dist);

@@ -247,6 +247,20 @@ int gdpso_vq_nearest(void *stream, int n, int d, int k, const float *inputs, con
                      long long *indices, float *codes, float *best_dist, void *workspace, size_t workspace_bytes);
 int gdpso_vq_lookup(void *stream, int n, int d, int k, const float *codebook, const long long *indices, float *codes);
 
+/* No counterpart in the reference: gdpso_vq_nearest for callers that cannot allocate device memory
+ * or hand over a workspace (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc).  Same inputs, outputs and results as gdpso_vq_nearest; the transposed
+ * codebook and its squared norms go to a static array inside the library instead of a caller
+ * workspace, so the call allocates and frees nothing.  Limit: gdpso_vq_workspace_bytes(k, d) <=
+ * GDPSO_VQ_STATIC_MAX_BYTES (e.g. K = 256 codes of D = 100: 103 KB), otherwise GDPSO_ERR_WORKSPACE.
+ * Every GPU the library runs on holds its own copy of the array until the process ends.  All
+ * calls on one GPU share that GPU's array: calls that overlap on one GPU (different streams or
+ * threads) race; calls on one stream, or otherwise ordered, are safe.  Every call rewrites all of
+ * the array it reads, so nothing has to be cleared between calls. */
+#define GDPSO_VQ_STATIC_MAX_BYTES (1u << 20)
+int gdpso_vq_nearest_static(void *stream, int n, int d, int k, const float *inputs, const float *codebook,
+                            long long *indices, float *codes, float *best_dist);
+
 /* -------------------------------------------------------------------- measurement
  * No counterpart in the reference: a hook for benchmarks.  Between begin and end, every
  * launch of the implicit-GEMM convolution kernel (generator, assessor and encoder

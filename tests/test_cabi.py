@@ -63,5 +63,8 @@ def test_argument_errors_without_gpu(lib):
     arr = (C.POINTER(C.c_float) * 1)()
     assert h.gdpso_assessor_create_resnet(C.byref(out), depths, 8, 28, arr, 1) == 1
     assert b"wrong number of tensors" in h.gdpso_last_error()
+    # the allocation-free search refuses sizes beyond its static scratch before touching the device
+    assert h.gdpso_vq_nearest_static(None, 1, 100, 4096, 1, 1, 1, None, None) == 3
+    assert b"static scratch" in h.gdpso_last_error()
     with pytest.raises(lib.GdpsoError):
         lib.check(1)
