@@ -32,7 +32,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X dense fp32-input MFMA (= fp32 vector peak)
+# MI355X dense matrix-instruction peaks by operand type: fp32-input MFMA (= the fp32 vector peak), and
+# the 16-bit forms (about 2.5 PFLOP/s dense; the headline figures twice that include 2:1 sparsity)
+PEAK_MFMA_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0}
 
 
 def cpu_baseline(z_dim, n_class, class_index, seconds_budget=20.0):
@@ -122,6 +124,9 @@ def main():
     ap.add_argument("--particles", type=int, default=512, help="particles per GPU")
     ap.add_argument("--z-dim", type=int, default=10)
     ap.add_argument("--side", type=int, default=28, help="image side (28: DCGAN-MNIST; 64: the CLARO-sized generator)")
+    ap.add_argument("--dtype", choices=sorted(PEAK_MFMA_TFLOPS), default="f32",
+                    help="storage / matrix-instruction input type of the networks (f32: the reference's precision and the headline "
+                         "configuration; bf16: the VQ-VAE-decoder configuration with --z-dim 100; f16: the 64x64 one with --side 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -171,8 +176,8 @@ def main():
         comm = eng.TorchComm()
 
     z_dim, n_class, class_index = args.z_dim, 8, 6
-    gen = eng.PackedGenerator(synth.generator_state(z_dim, 1, 64, seed=11, first_kernel=args.side // 4), dev)
-    ass = eng.PackedAssessor(synth.resnet_state("ResNet50", 1, n_class, seed=12), dev, img_side=gen.side)
+    gen = eng.PackedGenerator(synth.generator_state(z_dim, 1, 64, seed=11, first_kernel=args.side // 4), dev, dtype=args.dtype)
+    ass = eng.PackedAssessor(synth.resnet_state("ResNet50", 1, n_class, seed=12), dev, img_side=gen.side, dtype=args.dtype)
     ev = eng.Evaluator(gen, ass)
     spec = eng.FitnessSpec(class_index=class_index)
     p, k, w = args.particles, args.steps, args.warmup
@@ -260,13 +265,14 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")) as f:
                 pm = json.load(f)
-            if p == 512 and z_dim == 10 and args.side == 28:
+            if p == 512 and z_dim == 10 and args.side == 28 and args.dtype == "f32":
                 traffic = pm["kernels"]["conv_gemm (all instantiations)"]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
-        roofline = {"bound": "mfma", "kernel": "conv_gemm_kernel / conv_gemm_pair_kernel, all instantiations (fp32-input MFMA implicit GEMM)",
-                    "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+        peak = PEAK_MFMA_TFLOPS[args.dtype]
+        roofline = {"bound": "mfma", "kernel": f"conv_gemm_kernel / conv_gemm_pair_kernel / conv_gemm_fused_kernel, all instantiations ({args.dtype}-input MFMA implicit GEMM)",
+                    "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(achieved / peak, 4), "traffic": traffic,
                     "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_hbm_traffic.json)",
                     "algorithmic_bytes_per_launch": round(alg_bytes),
                     "launches_per_step": launches.value // k, "avg_launch_us": round(1e3 * ms.value / launches.value, 3),
@@ -274,7 +280,9 @@ def main():
                     "algorithmic_gflop_per_step": round(flops.value / k / 1e9, 3),
                     # what the MFMAs really multiplied: taps of border pixels that fall in the padding are skipped
                     "executed_gflop_per_step": round(executed / k / 1e9, 3),
-                    "executed_frac": round(executed / (ms.value * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+                    "executed_frac": round(executed / (ms.value * 1e-3) / 1e12 / peak, 4),
+                    # the same launches priced against HBM: algorithmic bytes over kernel time
+                    "algorithmic_tb_per_s": round(alg_bytes * launches.value / (ms.value * 1e-3) / 1e12, 3)}
     if comm is not None:
         comm.dist.barrier()
 
@@ -284,7 +292,7 @@ def main():
         out = {
             "metric": "particle-evaluations/sec (swarm x gen-fwd) DCGAN-MNIST", "value": round(value, 1),
             "unit": "particle-evals/s", "n_gpus": world, "steps": k, "warmup": w, "ms_per_step": round(1e3 * dt / k, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"DCGAN-MNIST {gen.side}x{gen.side}, {p} particles per GPU, ResNet50 assessor (n_class=8), z_dim={z_dim}, "
                                    f"{n_global} particles total", "particles_per_gpu": p, "z_dim": z_dim,
                        "flop_per_particle_eval": flop_per_eval, "parallelism": f"particle shards x{world}"},

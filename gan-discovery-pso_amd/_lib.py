@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(HERE, "libgdpso.so")
 
 ABI_VERSION = 1
 MODE_IN_TRAINING, MODE_OUT_TRAINING = 0, 1
+DTYPES = {"f32": 0, "bf16": 1, "f16": 2}  # GDPSO_DTYPE_*
 CTRL_DOUBLES = 8
 CTRL_W, CTRL_GBEST_VAL, CTRL_GBEST_IDX, CTRL_N_IMPROVE, CTRL_STOP_ITER, CTRL_ITERS_DONE = range(6)
 
@@ -53,12 +54,14 @@ _PROTOTYPES = {
     "gdpso_last_error": (C.c_char_p, []),
     "gdpso_struct_size": (c_size_t, [c_int]),
     "gdpso_generator_create": (c_int, [C.POINTER(c_void_p), c_int, c_int, c_int, FloatPP, c_int]),
+    "gdpso_generator_create_typed": (c_int, [C.POINTER(c_void_p), c_int, c_int, c_int, FloatPP, c_int, c_int]),
     "gdpso_generator_destroy": (None, [c_void_p]),
     "gdpso_generator_image_side": (c_int, [c_void_p]),
     "gdpso_generator_workspace_bytes": (c_size_t, [c_void_p, c_int]),
     "gdpso_generator_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_size_t]),
     "gdpso_assessor_create_resnet": (c_int, [C.POINTER(c_void_p), C.POINTER(c_int), c_int, c_int, FloatPP, c_int]),
+    "gdpso_assessor_create_resnet_typed": (c_int, [C.POINTER(c_void_p), C.POINTER(c_int), c_int, c_int, FloatPP, c_int, c_int]),
     "gdpso_assessor_destroy": (None, [c_void_p]),
     "gdpso_assessor_workspace_bytes": (c_size_t, [c_void_p, c_int]),
     "gdpso_assessor_n_class": (c_int, [c_void_p]),
@@ -88,6 +91,7 @@ _PROTOTYPES = {
     "gdpso_fast_div_check": (C.c_uint, [C.c_uint, C.c_uint]),
     "gdpso_conv_probe": (c_int, [c_int] * 11 + [C.POINTER(c_double), C.POINTER(c_int), C.POINTER(c_int)]),
     "gdpso_conv_layer_run": (c_int, [c_int] * 11 + [c_void_p] * 6 + [C.POINTER(c_int), C.POINTER(c_int)]),
+    "gdpso_conv_layer_run_typed": (c_int, [c_int] * 11 + [c_void_p] * 6 + [C.POINTER(c_int), C.POINTER(c_int), c_int]),
     "gdpso_swarm_iterate": (c_int, [C.POINTER(SwarmDesc), c_void_p, c_void_p, C.POINTER(RunDesc), c_void_p, c_int, c_int]),
 }
 

@@ -28,6 +28,58 @@ constexpr int MAX_TAPS = 64;   // 7x7 = 49 is the largest window on the path
 constexpr int MAX_PHASES = 16; // 3x3 border classes of a padded convolution, or 4 sub-pixel phases x 2x2 classes
 constexpr int PHASE_HDR = 12;  // ints ahead of the taps in a phase's device table
 
+// Storage / matrix-core input type of a network's activations and weights.  Accumulation, BatchNorm
+// scale / shift, residual adds and activations are always fp32.
+enum DType : int { DT_F32 = GDPSO_DTYPE_F32, DT_BF16 = GDPSO_DTYPE_BF16, DT_F16 = GDPSO_DTYPE_F16 };
+inline bool dtype_ok(int d) { return d == DT_F32 || d == DT_BF16 || d == DT_F16; }
+inline size_t dtype_size(int d) { return d == DT_F32 ? 4 : 2; }
+// K elements one wave consumes per K-tile (eight 16-byte fragments' worth along K per lane pair):
+// 32 floats or 64 half-width elements; channel counts must be multiples of it.
+inline int dtype_kquant(int d) { return d == DT_F32 ? 32 : 64; }
+
+// Element types of the reduced-precision instantiations, and four consecutive elements <-> four
+// floats (epilogues: residual in, result out; fp32 kernels that read or write 16-bit activations).
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using bf16_t = __bf16;
+using f16_t = _Float16;
+template <typename E>
+constexpr int vec_of() { return 16 / (int)sizeof(E); }  // elements per 16-byte vector
+template <typename E>
+constexpr bool is_f32() { return sizeof(E) == 4; }
+template <typename E>
+__device__ __forceinline__ f32x4 load4(const E *p) {  // p: global memory
+    if constexpr (is_f32<E>()) {
+        return *(const __attribute__((address_space(1))) f32x4 *)p;
+    } else {
+        using V = __attribute__((ext_vector_type(4))) E;
+        const V v = *(const __attribute__((address_space(1))) V *)p;
+        return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    }
+}
+template <typename E>
+__device__ __forceinline__ void store4(E *p, f32x4 v) {
+    if constexpr (is_f32<E>()) {
+        *(f32x4 *)p = v;
+    } else {
+        using V = __attribute__((ext_vector_type(4))) E;
+        *(V *)p = V{(E)v[0], (E)v[1], (E)v[2], (E)v[3]};
+    }
+}
+// Runs STMT with the type alias E bound to the element type of DTYPE.
+#define GDPSO_WITH_DTYPE(DTYPE, STMT)       \
+    do {                                    \
+        if ((DTYPE) == ::gdpso::DT_F32) {   \
+            using E = float;                \
+            STMT;                           \
+        } else if ((DTYPE) == ::gdpso::DT_BF16) { \
+            using E = ::gdpso::bf16_t;      \
+            STMT;                           \
+        } else {                            \
+            using E = ::gdpso::f16_t;       \
+            STMT;                           \
+        }                                   \
+    } while (0)
+
 // Activation applied in a convolution's epilogue.
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY02 = 2 };
 
@@ -61,11 +113,12 @@ struct ConvLayer {
     int nphase;
     int act;
     ConvPhase phase[MAX_PHASES];
-    const float *wt;     // device
+    int dtype;           // DType of the weights at `wt` and of the activations the layer reads and writes
+    const void *wt;      // device, elements of `dtype`
     const float *scale;  // device [cout] (never null)
     const float *shift;  // device [cout]
     const int *table;    // device [nphase][PHASE_HDR + MAX_TAPS], see upload_conv
-    size_t weight_floats;  // size of the packed weights
+    size_t weight_floats;  // elements of the packed weights
     // launch plan (chosen once per batch size by plan_conv)
     int tile;            // 128 or 64
     int splits;          // split-K factor
@@ -76,14 +129,15 @@ struct ConvLayer {
 int plan_conv(ConvLayer &L, int n_images, int num_cus);
 size_t conv_splitk_bytes(const ConvLayer &L, int n_images);
 int conv_splitk_prepare(hipStream_t stream, float *splitk_ws);
-int launch_conv(const ConvLayer &L, hipStream_t stream, int n_images, const float *in, const float *res,
-                float *out, float *splitk_ws);
+// in / res / out are NHWC arrays of the layer's dtype; splitk_ws holds fp32 partial sums.
+int launch_conv(const ConvLayer &L, hipStream_t stream, int n_images, const void *in, const void *res,
+                void *out, float *splitk_ws);
 
-int launch_conv_pair(const ConvLayer &La, const ConvLayer &Lb, hipStream_t stream, int n_images, const float *in,
-                     float *out_a, float *out_b, float *splitk_ws);
+int launch_conv_pair(const ConvLayer &La, const ConvLayer &Lb, hipStream_t stream, int n_images, const void *in,
+                     void *out_a, void *out_b, float *splitk_ws);
 
-int launch_conv_then_1x1(const ConvLayer &La, const ConvLayer &Lb, hipStream_t stream, int n_images, const float *in,
-                         float *mid, const float *res, float *out, float *splitk_ws);
+int launch_conv_then_1x1(const ConvLayer &La, const ConvLayer &Lb, hipStream_t stream, int n_images, const void *in,
+                         void *mid, const void *res, void *out, float *splitk_ws);
 
 // host-side helpers (pack.cpp)
 struct DeviceArena {
@@ -95,9 +149,14 @@ struct DeviceArena {
     }
 };
 
-// Uploads a layer's packed weights, scale/shift and tap table; fills the device pointers.
+// Uploads a layer's packed weights (rounded to `dtype`, round-to-nearest-even), scale/shift and tap
+// table; fills the device pointers and L.dtype.
 int upload_conv(DeviceArena &arena, ConvLayer &L, const std::vector<float> &packed,
-                const std::vector<float> &scale, const std::vector<float> &shift);
+                const std::vector<float> &scale, const std::vector<float> &shift, int dtype = DT_F32);
+
+// fp32 -> bf16 / fp16 bit patterns, round-to-nearest-even (host).
+uint16_t f32_to_bf16_bits(float v);
+uint16_t f32_to_f16_bits(float v);
 
 // Folds an eval-mode BatchNorm (and an optional preceding bias) into y = acc*scale + shift.
 void fold_bn(int c, const float *bias, const float *gamma, const float *beta, const float *mean,

@@ -39,22 +39,26 @@
 namespace gdpso {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
-using f32x4 = __attribute__((ext_vector_type(4))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 // Operand loads name the global address space: a generic (flat) load also counts against
 // lgkmcnt, so the LDS waits ahead of each barrier would drain the prefetch as well.
 using global_f32x4_ptr = const __attribute__((address_space(1))) f32x4 *;
 
-constexpr int BK = 32;
+// (bf16_t, f16_t, vec_of, is_f32, load4, store4: common.h.)  With v_mfma_f32_32x32x16_bf16 / _f16 a
+// lane's 16-byte fragment is the eight consecutive k of one instruction, so the tile code below is
+// the fp32 one with K counted in 16-byte vectors: VEC elements each, 4 floats or 8 half-width.
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+
 constexpr int PHASE_TABLE_INTS = PHASE_HDR + MAX_TAPS;  // header (see upload_conv) + packed taps
 
 struct ConvKArgs {
-    const float *in;
-    const float *wt;
+    const void *in;    // NHWC activations, elements of the instantiation's type
+    const void *wt;    // packed weights, same type
     const float *scale;
     const float *shift;
-    const float *res;
-    float *out;
+    const void *res;   // residual, same type as the activations, or null
+    void *out;
     float *part;       // split-K slabs [splits][pixels][cout], or null
     int *counters;     // split-K arrival counters, one per output tile (zero between launches), or null
     const int *table;  // [nphase][PHASE_TABLE_INTS]
@@ -75,7 +79,7 @@ struct ConvKArgs {
 
 // A 1x1 convolution over the same pixels, applied to this layer's output tile before it leaves
 // the workgroup (this layer has exactly 64 output channels = the whole K of the next one).
-struct FuseArgs {
+struct FuseArgs {  // fp32 instantiation only
     const float *wt;     // [cout][64]
     const float *scale;
     const float *shift;
@@ -140,7 +144,7 @@ struct StorePlan {
     f32x4 rres[PREFETCH_RES ? PASSES : 1];
 };
 
-template <int BM, int BN>
+template <typename E, int BM, int BN>
 __device__ __forceinline__ void conv_store_plan(const ConvKArgs &a, int tid, int m0, int n0, const PhaseInfo &P,
                                                 StorePlan<BM, BN> &sp) {
     using Plan = StorePlan<BM, BN>;
@@ -166,7 +170,7 @@ __device__ __forceinline__ void conv_store_plan(const ConvKArgs &a, int tid, int
 #pragma unroll
         for (int pass = 0; pass < Plan::PASSES; ++pass) {
             sp.rres[pass] = 0.f;
-            if (want) sp.rres[pass] = *(global_f32x4_ptr)(a.res + (sp.off[pass] < 0 ? col : sp.off[pass]));
+            if (want) sp.rres[pass] = load4<E>((const E *)a.res + (sp.off[pass] < 0 ? col : sp.off[pass]));
         }
     }
 }
@@ -178,9 +182,11 @@ __device__ __forceinline__ void conv_store_plan(const ConvKArgs &a, int tid, int
 // row segments, and the residual is read the same way.
 // KP > 1: the tile arrives as KP partial tiles (regions of BM x (BN + 4) floats, one per K part
 // of the workgroup), which are added in the order 0, 1, ... as they are read.
-template <int BM, int BN, int KP = 1>
+template <typename E, int BM, int BN, int KP = 1>
 __device__ __forceinline__ void conv_store_tile(const ConvKArgs &a, float *lds, int lds_floats, int tid, int sp, int tile,
                                                 const StorePlan<BM, BN> &plan) {
+    E *const out = (E *)a.out;
+    const E *const res = (const E *)a.res;
     using Plan = StorePlan<BM, BN>;
     constexpr int LDC = BN + 4;
     float *sC = lds;
@@ -205,15 +211,15 @@ __device__ __forceinline__ void conv_store_tile(const ConvKArgs &a, float *lds, 
                 v = v * sc + sh + plan.rres[pass];  // zeros without a residual
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = apply_slope(v[q], slope);
-                if (off[pass] >= 0) *(f32x4 *)(a.out + off[pass]) = v;
+                if (off[pass] >= 0) store4<E>(out + off[pass], v);
             } else {
                 if (off[pass] < 0) continue;
                 f32x4 v = tile_quad(pass * RPP + r0);
                 v = v * sc + sh;
-                if (a.res) v += *(const f32x4 *)(a.res + off[pass]);
+                if (res) v += load4<E>(res + off[pass]);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = apply_slope(v[q], slope);
-                *(f32x4 *)(a.out + off[pass]) = v;
+                store4<E>(out + off[pass], v);
             }
         }
         return;
@@ -264,32 +270,49 @@ __device__ __forceinline__ void conv_store_tile(const ConvKArgs &a, float *lds, 
 #pragma unroll 4
         for (int k = 1; k < a.splits; ++k) v += *(const f32x4 *)(a.part + (size_t)k * a.slab + off[pass]);
         v = v * sc + sh;
-        if (a.res) v += *(const f32x4 *)(a.res + off[pass]);
+        if (res) v += load4<E>(res + off[pass]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = apply_act(v[q], a.act);
-        *(f32x4 *)(a.out + off[pass]) = v;
+        store4<E>(out + off[pass], v);
     }
 }
 
-// BM x BN output tile, K-tiles of BKT floats.  KW = 1: the four waves form a 2 x 2 grid over the
+// One 32x32x16 matrix instruction on 16-bit operands: a lane's 16 bytes are its eight k
+// (k = 8 * (lane >> 5) + j) of row / column lane & 31.
+template <typename E>
+__device__ __forceinline__ f32x16 mfma16(const f32x4 &a, const f32x4 &b, const f32x16 &c) {
+    if constexpr (sizeof(E) == 4) {
+        return c;  // not used by the fp32 instantiation
+    } else if constexpr (__is_same(E, bf16_t)) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    } else {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+}
+
+// BM x BN output tile, K-tiles of BKT elements.  KW = 1: the four waves form a 2 x 2 grid over the
 // tile.  KW = 4 (32 x 32): every wave takes a quarter of each K-tile of the one 32 x 32 block.
 // KW = 2 (BM = 32): two waves side by side cover the tile and the other two take the
 // second half of every K-tile; the two halves are added through LDS before the epilogue.  That
 // shape doubles the number of workgroups of a small-M layer without split-K slabs.
-template <int BM, int BN, int BKT, int KW, bool FUSE = false>
+// E: element type of activations and weights (float, bf16_t, f16_t); BKT: elements per K-tile.
+template <typename E, int BM, int BN, int BKT, int KW, bool FUSE = false>
 __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, float *lds, const FuseArgs *fuse = nullptr) {
-    static_assert(!FUSE || (BM == 64 && BN == 64 && KW == 1), "the fused tail is written for the 64x64 tile");
-    static_assert(BKT / KW == 32, "every wave consumes 32 k per K-tile");
+    constexpr int VEC = vec_of<E>();  // elements per 16-byte vector
+    constexpr bool F32 = is_f32<E>();
+    static_assert(!FUSE || (BM == 64 && BN == 64 && KW == 1 && F32), "the fused tail is written for the fp32 64x64 tile");
+    static_assert(BKT / KW == 8 * VEC, "every wave consumes eight 16-byte vectors of k per K-tile (32 floats, 64 half-width elements)");
     static_assert(KW == 1 || BM == 32, "the K-split layout is for 32-row tiles");
-    constexpr int LDA = BKT + 4;  // 144- or 272-byte rows: ds_read_b128 of consecutive rows is conflict-free
+    constexpr int LDA = BKT + VEC;  // 144- or 272-byte rows: ds_read_b128 of consecutive rows is conflict-free
     static_assert(KW == 1 || BN * KW == 128, "K-split layouts: 32x64 over two wave pairs, 32x32 over four waves");
     constexpr int WM = KW == 1 ? BM / 64 : 1, WN = KW == 1 ? BN / 64 : 1;  // 32x32 MFMA blocks per wave
-    constexpr int RP = 256 / (BKT / 4);        // rows covered by one loader pass
+    constexpr int RP = 256 / (BKT / VEC);      // rows covered by one loader pass
     constexpr int PA = BM / RP, PB = BN / RP;  // loader passes
-    constexpr int LDS_FLOATS = 2 * (BM + BN) * LDA;
+    constexpr int LDS_FLOATS = 2 * (BM + BN) * LDA * (int)sizeof(E) / 4;
     static_assert(LDS_FLOATS >= BM * (BN + 4) + 4, "the output tile is staged in the operand buffers");
-    float *sA = lds;
-    float *sB = lds + 2 * BM * LDA;
+    E *sA = (E *)lds;
+    E *sB = sA + 2 * BM * LDA;
+    const E *const in = (const E *)a.in;
 
     GDPSO_STAMP(0)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -363,15 +386,15 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
     asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(wstride), "s"(ntaps) : "memory");  // the phase header has arrived
     GDPSO_STAMP(8)
 #endif
-    const float *wt = a.wt + tab[3];
+    const E *wt = (const E *)a.wt + tab[3];
     const int ktot = ntaps * a.cin;
     // this phase's K range per split (the divide only where K is split at all)
     const int ksplit = a.splits == 1 ? ktot : ((ktot / BKT + a.splits - 1) / a.splits) * BKT;
     const int kbeg = sp * ksplit;
     const int kend = min(ktot, kbeg + ksplit);
 
-    // loader coordinates: BKT/4 threads x 16 B cover one row of a K-tile
-    const int lrow = tid / (BKT / 4), lcol = (tid % (BKT / 4)) * 4;
+    // loader coordinates: BKT/VEC threads x 16 B cover one row of a K-tile
+    const int lrow = tid / (BKT / VEC), lcol = (tid % (BKT / VEC)) * VEC;
     int a_iy0[PA], a_ix0[PA], a_img[PA];
     bool a_ok[PA];
     const int hw = P.hm * P.wm;
@@ -391,8 +414,8 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
     // in layers too irregular to be split into border classes) and tail rows past M point
     // into the zero page and advance like the others.  A tap entry is
     // dy | dx << 8 | (position of the tap in the weight rows) << 16.
-    const float *aptr[PA], *bptr[PB];
-    const float *brow[PB];
+    const E *aptr[PA], *bptr[PB];
+    const E *brow[PB];
 #pragma unroll
     for (int p = 0; p < PB; ++p) brow[p] = wt + ((n0 + lrow + RP * p) * wstride + lcol);  // 32-bit offsets: see conv_args
     int tap = a.splits == 1 ? 0 : kbeg / a.cin, ci0 = kbeg - tap * a.cin;
@@ -404,8 +427,8 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
         _Pragma("unroll") for (int p = 0; p < PA; ++p) {                                                        \
             const int iy = a_iy0[p] + dy_, ix = a_ix0[p] + dx_;                                                 \
             const bool ok = a_ok[p] && (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;        \
-            aptr[p] = ok ? a.in + ((a_img[p] + iy * a.win + ix) * a.cin + (CI) + lcol)                          \
-                         : g_zero_page + (CI) + lcol;                                                           \
+            aptr[p] = ok ? in + ((a_img[p] + iy * a.win + ix) * a.cin + (CI) + lcol)                            \
+                         : (const E *)g_zero_page + (CI) + lcol;                                                \
         }                                                                                                       \
         _Pragma("unroll") for (int p = 0; p < PB; ++p) bptr[p] = brow[p] + wk_;                                 \
     }
@@ -443,15 +466,15 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
 #define GDPSO_SSTORE(BUF, S)                                                                                    \
     {                                                                                                           \
         _Pragma("unroll") for (int p = 0; p < PA; ++p)                                                          \
-            *(f32x4 *)&sA[(BUF) * BM * LDA + (lrow + RP * p) * LDA + lcol] = ra[S][p];                          \
+            *(f32x4 *)(void *)&sA[(BUF) * BM * LDA + (lrow + RP * p) * LDA + lcol] = ra[S][p];                  \
         _Pragma("unroll") for (int p = 0; p < PB; ++p)                                                          \
-            *(f32x4 *)&sB[(BUF) * BN * LDA + (lrow + RP * p) * LDA + lcol] = rb[S][p];                          \
+            *(f32x4 *)(void *)&sB[(BUF) * BN * LDA + (lrow + RP * p) * LDA + lcol] = rb[S][p];                  \
     }
-    // Operand fragments of MFMA group G (8 k's) into register set SET.
+    // Operand fragments of MFMA group G (two 16-byte vectors of k: one per lane half) into register set SET.
 #define GDPSO_LOADFRAG(SET, G)                                                                                  \
     {                                                                                                           \
-        _Pragma("unroll") for (int i = 0; i < WM; ++i) av[SET][i] = *(const f32x4 *)(pa + i * 32 * LDA + (G) * 8); \
-        _Pragma("unroll") for (int j = 0; j < WN; ++j) bv[SET][j] = *(const f32x4 *)(pb + j * 32 * LDA + (G) * 8); \
+        _Pragma("unroll") for (int i = 0; i < WM; ++i) av[SET][i] = *(const f32x4 *)(const void *)(pa + i * 32 * LDA + (G) * 2 * VEC); \
+        _Pragma("unroll") for (int j = 0; j < WN; ++j) bv[SET][j] = *(const f32x4 *)(const void *)(pb + j * 32 * LDA + (G) * 2 * VEC); \
     }
 
     f32x16 acc[WM][WN];
@@ -514,20 +537,28 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
 #define GDPSO_KSTEP(LOAD, LS, MORE, SS)                                                                         \
     {                                                                                                           \
         if ((LOAD) && GDPSO_DBG(2)) GDPSO_GISSUE(LS)                                                            \
-        const float *pa = sA + buf * BM * LDA + (wr * (BM / 2) + l31) * LDA + half * 4 + kh * 32;               \
-        const float *pb = sB + buf * BN * LDA + (wc * (BN / 2) + l31) * LDA + half * 4 + kh * 32;               \
+        const E *pa = sA + buf * BM * LDA + (wr * (BM / 2) + l31) * LDA + half * VEC + kh * 8 * VEC;           \
+        const E *pb = sB + buf * BN * LDA + (wc * (BN / 2) + l31) * LDA + half * VEC + kh * 8 * VEC;           \
         f32x4 av[2][WM], bv[2][WN];                                                                             \
         GDPSO_LOADFRAG(0, 0)                                                                                    \
         _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                         \
             if (g < 3) GDPSO_LOADFRAG((g + 1) & 1, g + 1)                                                       \
             if (g == 3 && (MORE) && GDPSO_DBG(4)) GDPSO_SSTORE(buf ^ 1, SS)                                     \
-            _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                       \
+            if constexpr (F32) {                                                                                \
+                _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                   \
+                    _Pragma("unroll") for (int i = 0; i < WM; ++i)                                              \
+                        _Pragma("unroll") for (int j = 0; j < WN; ++j)                                          \
+                            if (GDPSO_DBG(1))                                                                   \
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1][i][s], bv[g & 1][j][s], acc[i][j], 0, 0, 0); \
+            } else {                                                                                            \
                 _Pragma("unroll") for (int i = 0; i < WM; ++i)                                                  \
                     _Pragma("unroll") for (int j = 0; j < WN; ++j)                                              \
-                        if (GDPSO_DBG(1))                                                                       \
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1][i][s], bv[g & 1][j][s], acc[i][j], 0, 0, 0); \
+                        acc[i][j] = mfma16<E>(av[g & 1][i], bv[g & 1][j], acc[i][j]);                           \
+            }                                                                                                   \
         }                                                                                                       \
-        if constexpr (WM * WN == 1) {                                                                           \
+        if constexpr (!F32) {                                                                                   \
+            /* 16-bit: a K-step is 4 (or 16) short MFMAs; the compiler's own schedule is kept */                 \
+        } else if constexpr (WM * WN == 1) {                                                                    \
             constexpr int NV = (LOAD) ? PA + PB : 0, NW = (MORE) ? PA + PB : 0;                                 \
             GDPSO_SGB(0x100, 2)                                                                                 \
             GDPSO_SGB(0x008, 1) GDPSO_SGB(0x100, 2)                                                             \
@@ -675,7 +706,7 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
     constexpr int LDC = BN + 4;
     float *sC = lds;
     StorePlan<BM, BN> plan;
-    conv_store_plan<BM, BN>(a, tid, m0, n0, P, plan);
+    conv_store_plan<E, BM, BN>(a, tid, m0, n0, P, plan);
     if (KW == 1) {
 #pragma unroll
         for (int i = 0; i < WM; ++i)
@@ -694,62 +725,59 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
             sC[kh * REGION + ((r & 3) + 8 * (r >> 2) + 4 * half) * LDC + wc * 32 + l31] = acc[0][0][r];
     }
     __syncthreads();
-    conv_store_tile<BM, BN, KW>(a, lds, LDS_FLOATS, tid, sp, tile, plan);
+    conv_store_tile<E, BM, BN, KW>(a, lds, LDS_FLOATS, tid, sp, tile, plan);
 #ifdef GDPSO_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have left the CU
     GDPSO_STAMP(3)
 #endif
 }
 
-template <int BM, int BN, int BKT, int KW>
+// BKB: bytes of K per K-tile row (128, 256 or 512); the K-tile holds BKB / sizeof(E) elements.
+template <typename E, int BM, int BN, int BKB, int KW>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * (BKT + 4)];
-    conv_tile<BM, BN, BKT, KW>(a, blockIdx.x, lds);
+    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * (BKB / 4 + 4)];
+    conv_tile<E, BM, BN, BKB / (int)sizeof(E), KW>(a, blockIdx.x, lds);
 }
 
 // A convolution with 64 output channels followed by a 1x1 convolution, one launch: conv2 + conv3
 // of the first-stage bottleneck blocks.  The intermediate never leaves the workgroup.
 __global__ __launch_bounds__(256, 2) void conv_gemm_fused_kernel(const ConvKArgs a, const FuseArgs f) {
     __shared__ __attribute__((aligned(16))) float lds[3 * 64 * 68];
-    conv_tile<64, 64, 32, 1, true>(a, blockIdx.x, lds, &f);
+    conv_tile<float, 64, 64, 32, 1, true>(a, blockIdx.x, lds, &f);
 }
 
 // Two independent layers in one grid (same tile shape, no split-K): the first tiles_a workgroups
 // (a multiple of 8, so that both layers see workgroup index & 7 == XCD) belong to layer a, the
 // rest to layer b.  Used for identity_downsample + conv1 of a bottleneck block, which read the
 // same input: one launch, one fill and drain, and the tail of one layer overlaps the other.
-template <int BM, int BN, int BKT, int KW>
+template <typename E, int BM, int BN, int BKB, int KW>
 __global__ __launch_bounds__(256, 2) void conv_gemm_pair_kernel(const ConvKArgs a, const ConvKArgs b, int tiles_a) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * (BKT + 4)];
+    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * (BKB / 4 + 4)];
     // two copies of the tile code, each reading its own kernel arguments straight from SGPRs
     if ((int)blockIdx.x < tiles_a)
-        conv_tile<BM, BN, BKT, KW>(a, blockIdx.x, lds);
+        conv_tile<E, BM, BN, BKB / (int)sizeof(E), KW>(a, blockIdx.x, lds);
     else
-        conv_tile<BM, BN, BKT, KW>(b, blockIdx.x - tiles_a, lds);
+        conv_tile<E, BM, BN, BKB / (int)sizeof(E), KW>(b, blockIdx.x - tiles_a, lds);
 }
 
-// Sums the split-K slabs and applies the epilogue.  One float4 (4 channels) per thread.
+// Sums the split-K slabs and applies the epilogue.  Four channels per thread.
+template <typename E>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ part, int splits, long slab,
                                                             int cout, const float *__restrict__ scale,
                                                             const float *__restrict__ shift,
-                                                            const float *__restrict__ res, float *__restrict__ out,
+                                                            const E *__restrict__ res, E *__restrict__ out,
                                                             int act) {
     const long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (e >= slab) return;
-    float4 s = *(const float4 *)(part + e);
-    for (int k = 1; k < splits; ++k) {
-        const float4 t = *(const float4 *)(part + (size_t)k * slab + e);
-        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
-    }
+    f32x4 s = *(const f32x4 *)(part + e);
+    for (int k = 1; k < splits; ++k) s += *(const f32x4 *)(part + (size_t)k * slab + e);
     const int c = (int)(e % cout);
-    const float4 sc = *(const float4 *)(scale + c), sh = *(const float4 *)(shift + c);
-    float4 v = make_float4(s.x * sc.x + sh.x, s.y * sc.y + sh.y, s.z * sc.z + sh.z, s.w * sc.w + sh.w);
-    if (res) {
-        const float4 r = *(const float4 *)(res + e);
-        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-    }
-    v.x = apply_act(v.x, act); v.y = apply_act(v.y, act); v.z = apply_act(v.z, act); v.w = apply_act(v.w, act);
-    *(float4 *)(out + e) = v;
+    const f32x4 sc = *(const f32x4 *)(scale + c), sh = *(const f32x4 *)(shift + c);
+    f32x4 v = s * sc + sh;
+    if (res) v += load4<E>(res + e);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = apply_act(v[q], act);
+    store4<E>(out + e, v);
 }
 
 // --------------------------------------------------------------------------- host side
@@ -830,9 +858,10 @@ int plan_conv(ConvLayer &L, int n_images, int num_cus) {
     if (L.cout % L.tile != 0) return fail(GDPSO_ERR_ARG, "conv: cout must be a multiple of 64");
     // at most one 64x64 tile per CU: 32-row tiles double the workgroups without slabs (measured:
     // a gain up to 256 tiles, a loss at 392)
-    if (L.tile == 64 && g_allow_tile32 && L.cin % 64 == 0 && m_tiles(L, n_images, 64) * (L.cout / 64) <= (long)num_cus) L.tile = 32;
+    const int kq = dtype_kquant(L.dtype);  // k per wave per K-tile: the K-split tiles need 2 and 4 of them per tap
+    if (L.tile == 64 && g_allow_tile32 && L.cin % (2 * kq) == 0 && m_tiles(L, n_images, 64) * (L.cout / 64) <= (long)num_cus) L.tile = 32;
     // still at most one workgroup per CU: 32x32 tiles with the K-tile split four ways double them again
-    if (L.tile == 32 && L.cin % 128 == 0 && m_tiles(L, n_images, 32) * (L.cout / 64) <= (long)num_cus) L.tile = TILE_32x32;
+    if (L.tile == 32 && L.cin % (4 * kq) == 0 && m_tiles(L, n_images, 32) * (L.cout / 64) <= (long)num_cus) L.tile = TILE_32x32;
     const long tiles = m_tiles(L, n_images, L.tile) * (L.cout / tile_bn(L.tile));
     const long ktot = max_ktot(L);
     int splits = 1;
@@ -860,8 +889,9 @@ int conv_splitk_prepare(hipStream_t stream, float *splitk_ws) {
 }
 
 // Fills the kernel arguments of one layer; returns its number of workgroups per split through *tiles.
-static int conv_args(const ConvLayer &L, int n_images, const float *in, const float *res, float *out, float *splitk_ws,
+static int conv_args(const ConvLayer &L, int n_images, const void *in, const void *res, void *out, float *splitk_ws,
                      ConvKArgs &a, long *grid_x, bool *fused_reduce) {
+    if (!dtype_ok(L.dtype)) return fail(GDPSO_ERR_ARG, "conv: unknown element type");
     a.in = in; a.wt = L.wt; a.scale = L.scale; a.shift = L.shift; a.res = res; a.out = out;
     const long tiles_m = m_tiles(L, n_images, L.tile);
     const long tiles_total = tiles_m * (L.cout / tile_bn(L.tile));
@@ -895,15 +925,16 @@ static int conv_args(const ConvLayer &L, int n_images, const float *in, const fl
     a.tiles_n_mul = dn.mul;
     a.tiles_n_shift = dn.shift;
     a.slab = (long)n_images * L.hout * L.wout * L.cout;
-    if (L.cin % BK != 0 || L.cin > MAX_CIN) return fail(GDPSO_ERR_ARG, "conv: cin must be a multiple of 32, at most 4096");
+    const int kq = dtype_kquant(L.dtype);
+    if (L.cin % kq != 0 || L.cin > MAX_CIN) return fail(GDPSO_ERR_ARG, "conv: cin must be a multiple of 32 (fp32) or 64 (16-bit), at most 4096");
     if (L.splits > 1 && !splitk_ws) return fail(GDPSO_ERR_WORKSPACE, "conv: split-K workspace missing");
     if (a.slab * 4 >= (1L << 31)) return fail(GDPSO_ERR_ARG, "conv: output larger than 2 GiB");
     // the kernel forms element offsets into the input and the weights in 32 bits
     if ((long)n_images * L.hin * L.win * L.cin * 4 >= (1L << 31)) return fail(GDPSO_ERR_ARG, "conv: input larger than 2 GiB");
     if ((long)L.weight_floats * 4 >= (1L << 31)) return fail(GDPSO_ERR_ARG, "conv: weights larger than 2 GiB");
     if (tiles_total >= (1L << 30) || (long)n_images * L.hout * L.wout >= (1L << 31)) return fail(GDPSO_ERR_ARG, "conv: too many rows");
-    if (L.tile == 32 && L.cin % 64 != 0) return fail(GDPSO_ERR_ARG, "conv: the 32-row tile needs cin to be a multiple of 64");
-    if (L.tile == TILE_32x32 && L.cin % 128 != 0) return fail(GDPSO_ERR_ARG, "conv: the 32x32 tile needs cin to be a multiple of 128");
+    if (L.tile == 32 && L.cin % (2 * kq) != 0) return fail(GDPSO_ERR_ARG, "conv: the 32-row tile needs cin to be a multiple of 64 (fp32) or 128 (16-bit)");
+    if (L.tile == TILE_32x32 && L.cin % (4 * kq) != 0) return fail(GDPSO_ERR_ARG, "conv: the 32x32 tile needs cin to be a multiple of 128 (fp32) or 256 (16-bit)");
     return GDPSO_OK;
 }
 
@@ -911,11 +942,11 @@ static void conv_account(const ConvLayer &L, int n_images, const ConvKArgs &a, b
     g_timing.flops += L.flops_nominal * n_images;
     for (int p = 0; p < L.nphase; ++p)
         g_timing.executed += 2.0 * n_images * L.phase[p].hm * L.phase[p].wm * (double)L.phase[p].ntaps * L.cin * L.cout;
-    g_timing.bytes += 4.0 * ((double)n_images * L.hin * L.win * L.cin + (double)L.weight_floats + (double)a.slab * (has_res ? 2 : 1));
+    g_timing.bytes += (double)dtype_size(L.dtype) * ((double)n_images * L.hin * L.win * L.cin + (double)L.weight_floats + (double)a.slab * (has_res ? 2 : 1));
 }
 
-int launch_conv(const ConvLayer &L, hipStream_t stream, int n_images, const float *in, const float *res,
-                float *out, float *splitk_ws) {
+int launch_conv(const ConvLayer &L, hipStream_t stream, int n_images, const void *in, const void *res,
+                void *out, float *splitk_ws) {
     ConvKArgs a;
     long tiles_total = 0;
     bool fused_reduce = false;
@@ -932,15 +963,24 @@ int launch_conv(const ConvLayer &L, hipStream_t stream, int n_images, const floa
         hipExtLaunchKernelGGL((KERNEL), grid, dim3(256), 0, stream, e0, e1, 0, a);           \
     else                                                                                     \
         hipLaunchKernelGGL((KERNEL), grid, dim3(256), 0, stream, a);
-    if (L.tile == 128) {
-        GDPSO_LAUNCH((conv_gemm_kernel<128, 128, 32, 1>))
-    } else if (L.tile == 64) {
-        GDPSO_LAUNCH((conv_gemm_kernel<64, 64, 32, 1>))
-    } else if (L.tile == 32) {
-        GDPSO_LAUNCH((conv_gemm_kernel<32, 64, 64, 2>))
-    } else {
-        GDPSO_LAUNCH((conv_gemm_kernel<32, 32, 128, 4>))
+#define GDPSO_LAUNCH_TILES(E)                                       \
+    if (L.tile == 128) {                                            \
+        GDPSO_LAUNCH((conv_gemm_kernel<E, 128, 128, 128, 1>))       \
+    } else if (L.tile == 64) {                                      \
+        GDPSO_LAUNCH((conv_gemm_kernel<E, 64, 64, 128, 1>))         \
+    } else if (L.tile == 32) {                                      \
+        GDPSO_LAUNCH((conv_gemm_kernel<E, 32, 64, 256, 2>))         \
+    } else {                                                        \
+        GDPSO_LAUNCH((conv_gemm_kernel<E, 32, 32, 512, 4>))         \
     }
+    if (L.dtype == DT_F32) {
+        GDPSO_LAUNCH_TILES(float)
+    } else if (L.dtype == DT_BF16) {
+        GDPSO_LAUNCH_TILES(bf16_t)
+    } else {
+        GDPSO_LAUNCH_TILES(f16_t)
+    }
+#undef GDPSO_LAUNCH_TILES
 #undef GDPSO_LAUNCH
     if (timed) {
         g_timing.used += 2;
@@ -948,8 +988,16 @@ int launch_conv(const ConvLayer &L, hipStream_t stream, int n_images, const floa
     }
     if (L.splits > 1 && !fused_reduce) {
         const long quads = a.slab / 4;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ceil_div(quads, 256)), dim3(256), 0, stream, a.part, L.splits,
-                           a.slab, L.cout, L.scale, L.shift, res, out, L.act);
+        const dim3 rgrid(ceil_div(quads, 256));
+        if (L.dtype == DT_F32)
+            hipLaunchKernelGGL(splitk_reduce_kernel<float>, rgrid, dim3(256), 0, stream, a.part, L.splits, a.slab, L.cout, L.scale,
+                               L.shift, (const float *)res, (float *)out, L.act);
+        else if (L.dtype == DT_BF16)
+            hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, rgrid, dim3(256), 0, stream, a.part, L.splits, a.slab, L.cout, L.scale,
+                               L.shift, (const bf16_t *)res, (bf16_t *)out, L.act);
+        else
+            hipLaunchKernelGGL(splitk_reduce_kernel<f16_t>, rgrid, dim3(256), 0, stream, a.part, L.splits, a.slab, L.cout, L.scale,
+                               L.shift, (const f16_t *)res, (f16_t *)out, L.act);
     }
     GDPSO_HIP(hipGetLastError());
     return GDPSO_OK;
@@ -957,9 +1005,9 @@ int launch_conv(const ConvLayer &L, hipStream_t stream, int n_images, const floa
 
 // La (64 output channels, 64x64 tiles, unsplit) followed by the 1x1 convolution Lb over the same
 // pixels, in one launch when the shapes allow; `mid` receives La's output only on the fallback path.
-int launch_conv_then_1x1(const ConvLayer &La, const ConvLayer &Lb, hipStream_t stream, int n_images, const float *in,
-                         float *mid, const float *res, float *out, float *splitk_ws) {
-    const bool ok = g_fuse_1x1 && La.tile == 64 && La.splits == 1 && La.cout == 64 && Lb.cin == 64 && Lb.nphase == 1 &&
+int launch_conv_then_1x1(const ConvLayer &La, const ConvLayer &Lb, hipStream_t stream, int n_images, const void *in,
+                         void *mid, const void *res, void *out, float *splitk_ws) {
+    const bool ok = g_fuse_1x1 && La.dtype == DT_F32 && Lb.dtype == DT_F32 && La.tile == 64 && La.splits == 1 && La.cout == 64 && Lb.cin == 64 && Lb.nphase == 1 &&
                     Lb.phase[0].ntaps == 1 && Lb.in_stride == 1 && Lb.out_mul == 1 && Lb.hout == La.hout && Lb.wout == La.wout &&
                     Lb.cout % 64 == 0 && Lb.phase[0].wstride == 64;
     if (!ok) {
@@ -973,7 +1021,8 @@ int launch_conv_then_1x1(const ConvLayer &La, const ConvLayer &Lb, hipStream_t s
     int rc = conv_args(La, n_images, in, nullptr, nullptr, splitk_ws, a, &tiles, &fr);
     if (rc) return rc;
     FuseArgs f;
-    f.wt = Lb.wt; f.scale = Lb.scale; f.shift = Lb.shift; f.res = res; f.out = out; f.cout = Lb.cout; f.act = Lb.act;
+    f.wt = (const float *)Lb.wt; f.scale = Lb.scale; f.shift = Lb.shift; f.res = (const float *)res; f.out = (float *)out;
+    f.cout = Lb.cout; f.act = Lb.act;
     if ((long)n_images * Lb.hout * Lb.wout * Lb.cout * 4 >= (1L << 31)) return fail(GDPSO_ERR_ARG, "conv: output larger than 2 GiB");
     dim3 grid((unsigned)tiles, 1, 1);
     const bool timed = g_timing.on && g_timing.used + 2 <= g_timing.events.size();
@@ -995,9 +1044,9 @@ int launch_conv_then_1x1(const ConvLayer &La, const ConvLayer &Lb, hipStream_t s
 
 // Two layers that read the same input, in one launch (see conv_gemm_pair_kernel).  Falls back
 // to two launches when the planner gave them different shapes or either is split.
-int launch_conv_pair(const ConvLayer &La, const ConvLayer &Lb, hipStream_t stream, int n_images, const float *in,
-                     float *out_a, float *out_b, float *splitk_ws) {
-    if (!g_pair_launch || La.tile != Lb.tile || La.tile == TILE_32x32 || La.splits != 1 || Lb.splits != 1) {
+int launch_conv_pair(const ConvLayer &La, const ConvLayer &Lb, hipStream_t stream, int n_images, const void *in,
+                     void *out_a, void *out_b, float *splitk_ws) {
+    if (!g_pair_launch || La.dtype != Lb.dtype || La.tile != Lb.tile || La.tile == TILE_32x32 || La.splits != 1 || Lb.splits != 1) {
         int rc = launch_conv(La, stream, n_images, in, nullptr, out_a, splitk_ws);
         if (rc) return rc;
         return launch_conv(Lb, stream, n_images, in, nullptr, out_b, splitk_ws);
@@ -1017,19 +1066,28 @@ int launch_conv_pair(const ConvLayer &La, const ConvLayer &Lb, hipStream_t strea
         hipExtLaunchKernelGGL((KERNEL), grid, dim3(256), 0, stream, e0, e1, 0, a, b, (int)ta);         \
     else                                                                                              \
         hipLaunchKernelGGL((KERNEL), grid, dim3(256), 0, stream, a, b, (int)ta);
-    if (La.tile == 128) {
-        GDPSO_LAUNCH((conv_gemm_pair_kernel<128, 128, 32, 1>))
-    } else if (La.tile == 64) {
-        GDPSO_LAUNCH((conv_gemm_pair_kernel<64, 64, 32, 1>))
-    } else {
-        GDPSO_LAUNCH((conv_gemm_pair_kernel<32, 64, 64, 2>))
+#define GDPSO_LAUNCH_TILES(E)                                       \
+    if (La.tile == 128) {                                           \
+        GDPSO_LAUNCH((conv_gemm_pair_kernel<E, 128, 128, 128, 1>))  \
+    } else if (La.tile == 64) {                                     \
+        GDPSO_LAUNCH((conv_gemm_pair_kernel<E, 64, 64, 128, 1>))    \
+    } else {                                                        \
+        GDPSO_LAUNCH((conv_gemm_pair_kernel<E, 32, 64, 256, 2>))    \
     }
+    if (La.dtype == DT_F32) {
+        GDPSO_LAUNCH_TILES(float)
+    } else if (La.dtype == DT_BF16) {
+        GDPSO_LAUNCH_TILES(bf16_t)
+    } else {
+        GDPSO_LAUNCH_TILES(f16_t)
+    }
+#undef GDPSO_LAUNCH_TILES
 #undef GDPSO_LAUNCH
     if (timed) {
         g_timing.used += 2;
         conv_account(La, n_images, a, false);
         conv_account(Lb, n_images, b, false);
-        g_timing.bytes -= 4.0 * n_images * La.hin * La.win * La.cin;  // the shared input is read once
+        g_timing.bytes -= (double)dtype_size(La.dtype) * n_images * La.hin * La.win * La.cin;  // the shared input is read once
     }
     GDPSO_HIP(hipGetLastError());
     return GDPSO_OK;
@@ -1184,23 +1242,39 @@ extern "C" int gdpso_conv_probe(int n_images, int hin, int cin, int cout, int ks
     return GDPSO_OK;
 }
 
+// Element-wise casts between fp32 arrays and the 16-bit storage types (round to nearest even).
+template <typename E>
+__global__ __launch_bounds__(256) void cast_from_f32_kernel(const float *__restrict__ in, E *__restrict__ out, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (E)in[i];
+}
+template <typename E>
+__global__ __launch_bounds__(256) void cast_to_f32_kernel(const E *__restrict__ in, float *__restrict__ out, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (float)in[i];
+}
+
 // Runs ONE convolution layer on the caller's data (test aid: lets a test drive every tile
 // shape and split count on arbitrary layer shapes, which whole-network tests reach only by
 // way of the planner).  weight/scale/shift are host arrays (weight in PyTorch layout:
 // [cout][cin][k][k], or [cin][cout][4][4] when `transposed`, which means ConvTranspose2d
-// k4 s2 p1); in/res/out are device NHWC arrays.  tile = 0 / splits = 0 keep the planner's
-// choice.  Allocates and frees its own device copies; synchronises before returning.
-extern "C" int gdpso_conv_layer_run(int n_images, int hin, int cin, int cout, int ksize, int stride, int pad,
-                                    int transposed, int act, int tile, int splits, const float *weight,
-                                    const float *scale, const float *shift, const float *in, const float *res,
-                                    float *out, int *tile_used, int *splits_used) {
+// k4 s2 p1); in/res/out are device NHWC fp32 arrays.  tile = 0 / splits = 0 keep the planner's
+// choice.  With a 16-bit dtype the layer runs on copies of in / res rounded to that type and
+// its output is widened back into `out`.  Allocates and frees its own device copies;
+// synchronises before returning.
+extern "C" int gdpso_conv_layer_run_typed(int n_images, int hin, int cin, int cout, int ksize, int stride, int pad,
+                                          int transposed, int act, int tile, int splits, const float *weight,
+                                          const float *scale, const float *shift, const float *in, const float *res,
+                                          float *out, int *tile_used, int *splits_used, int dtype) {
     using namespace gdpso;
-    GDPSO_REQUIRE(n_images > 0 && hin > 0 && cin > 0 && cin % 32 == 0 && cout > 0 && cout % 64 == 0, "conv_layer_run: bad shape");
+    GDPSO_REQUIRE(dtype_ok(dtype), "conv_layer_run: unknown dtype");
+    const int kq = dtype_kquant(dtype);
+    GDPSO_REQUIRE(n_images > 0 && hin > 0 && cin > 0 && cin % kq == 0 && cout > 0 && cout % 64 == 0, "conv_layer_run: bad shape");
     GDPSO_REQUIRE(weight && scale && shift && in && out, "conv_layer_run: null pointer");
     GDPSO_REQUIRE(act == ACT_NONE || act == ACT_RELU || act == ACT_LEAKY02, "conv_layer_run: bad activation");
     GDPSO_REQUIRE(transposed || (ksize > 0 && stride > 0 && pad >= 0 && hin + 2 * pad >= ksize), "conv_layer_run: bad window");
     GDPSO_REQUIRE(transposed || conv_window_fits(ksize, pad), "conv_layer_run: window too large (at most 64 taps, offsets within +-127)");
-    GDPSO_REQUIRE(tile == 0 || tile == 64 || (tile == 32 && cin % 64 == 0) || (tile == TILE_32x32 && cin % 128 == 0) ||
+    GDPSO_REQUIRE(tile == 0 || tile == 64 || (tile == 32 && cin % (2 * kq) == 0) || (tile == TILE_32x32 && cin % (4 * kq) == 0) ||
                       (tile == 128 && cout % 128 == 0),
                   "conv_layer_run: bad tile");
     GDPSO_REQUIRE(splits >= 0 && splits <= 16, "conv_layer_run: bad split count");
@@ -1211,7 +1285,7 @@ extern "C" int gdpso_conv_layer_run(int n_images, int hin, int cin, int cout, in
     else
         make_conv(L, weight, cout, cin, ksize, ksize, stride, pad, hin, hin, (Act)act, packed);
     DeviceArena arena;
-    int rc = upload_conv(arena, L, packed, sc, sh);
+    int rc = upload_conv(arena, L, packed, sc, sh, dtype);
     if (rc) return rc;
     int dev = 0, cus = 256;
     GDPSO_HIP(hipGetDevice(&dev));
@@ -1223,9 +1297,37 @@ extern "C" int gdpso_conv_layer_run(int n_images, int hin, int cin, int cout, in
     GDPSO_HIP(hipMalloc(&d_sk, conv_splitk_bytes(L, n_images)));
     arena.blocks.push_back(d_sk);
     GDPSO_HIP(hipMemset(d_sk, 0, SPLITK_COUNTER_BYTES));
-    if ((rc = launch_conv(L, nullptr, n_images, in, res, out, d_sk))) return rc;
+    const long n_in = (long)n_images * hin * hin * cin, n_out = (long)n_images * L.hout * L.wout * cout;
+    const void *k_in = in, *k_res = res;
+    void *k_out = out;
+    if (dtype != DT_F32) {
+        void *p_in = nullptr, *p_res = nullptr, *p_out = nullptr;
+        GDPSO_HIP(hipMalloc(&p_in, n_in * 2));
+        arena.blocks.push_back(p_in);
+        GDPSO_HIP(hipMalloc(&p_out, n_out * 2));
+        arena.blocks.push_back(p_out);
+        GDPSO_WITH_DTYPE(dtype, hipLaunchKernelGGL(cast_from_f32_kernel<E>, dim3(ceil_div(n_in, 256)), dim3(256), 0, nullptr, in, (E *)p_in, n_in));
+        if (res) {
+            GDPSO_HIP(hipMalloc(&p_res, n_out * 2));
+            arena.blocks.push_back(p_res);
+            GDPSO_WITH_DTYPE(dtype, hipLaunchKernelGGL(cast_from_f32_kernel<E>, dim3(ceil_div(n_out, 256)), dim3(256), 0, nullptr, res, (E *)p_res, n_out));
+        }
+        k_in = p_in; k_res = p_res; k_out = p_out;
+    }
+    if ((rc = launch_conv(L, nullptr, n_images, k_in, k_res, k_out, d_sk))) return rc;
+    if (dtype != DT_F32)
+        GDPSO_WITH_DTYPE(dtype, hipLaunchKernelGGL(cast_to_f32_kernel<E>, dim3(ceil_div(n_out, 256)), dim3(256), 0, nullptr, (const E *)k_out, out, n_out));
+    GDPSO_HIP(hipGetLastError());
     GDPSO_HIP(hipStreamSynchronize(nullptr));
     if (tile_used) *tile_used = L.tile;
     if (splits_used) *splits_used = L.splits;
     return GDPSO_OK;
+}
+
+extern "C" int gdpso_conv_layer_run(int n_images, int hin, int cin, int cout, int ksize, int stride, int pad,
+                                    int transposed, int act, int tile, int splits, const float *weight,
+                                    const float *scale, const float *shift, const float *in, const float *res,
+                                    float *out, int *tile_used, int *splits_used) {
+    return gdpso_conv_layer_run_typed(n_images, hin, cin, cout, ksize, stride, pad, transposed, act, tile, splits, weight, scale,
+                                      shift, in, res, out, tile_used, splits_used, GDPSO_DTYPE_F32);
 }

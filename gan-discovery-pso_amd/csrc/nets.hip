@@ -12,14 +12,15 @@ namespace gdpso {
 // ---------------------------------------------------------------------------------
 // Latents: float64 (or float32) positions -> float32 rows zero-padded to the GEMM's K.
 // The float64 -> float32 cast is the one at reference src/pso/util_discovery.py:41-43.
+template <typename E>
 __global__ __launch_bounds__(256) void latent_prep_kernel(const void *__restrict__ z, int z_is_f64, int n, int zd,
-                                                          int kpad, float *__restrict__ out) {
+                                                          int kpad, E *__restrict__ out) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= (long)n * kpad) return;
     const int row = (int)(e / kpad), col = (int)(e - (long)row * kpad);
     float v = 0.f;
     if (col < zd) v = z_is_f64 ? (float)((const double *)z)[(long)row * zd + col] : ((const float *)z)[(long)row * zd + col];
-    out[e] = v;
+    out[e] = (E)v;
 }
 
 // ---------------------------------------------------------------------------------
@@ -31,10 +32,9 @@ __global__ __launch_bounds__(256) void latent_prep_kernel(const void *__restrict
 // the four output phases (oy&1, ox&1) are processed one after the other so that the
 // 2x2 kernel taps of a phase are wave-uniform and live in registers.  16 lanes share one
 // output pixel (4 channels each, one 16-byte read per tap) and reduce by shuffles.
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-
-template <bool STAGED>
-__global__ __launch_bounds__(512) void gen_last_kernel(const float *__restrict__ a2, const float *__restrict__ w5,
+// E: element type of the incoming activations (the arithmetic is fp32 whatever it is).
+template <bool STAGED, typename E>
+__global__ __launch_bounds__(512) void gen_last_kernel(const E *__restrict__ a2, const float *__restrict__ w5,
                                                        float bias, int hin, int cin, float *__restrict__ img,
                                                        float *__restrict__ img01, const float *__restrict__ target,
                                                        float *__restrict__ mse) {
@@ -44,12 +44,18 @@ __global__ __launch_bounds__(512) void gen_last_kernel(const float *__restrict__
     float *s_red = s_img + npix;    // [3][8]: min, max, squared error of the 8 waves
     float *s_a2 = s_red + 32;       // [nin][cin] when STAGED
     const int tid = threadIdx.x, n = blockIdx.x;
-    const float *src = a2 + (size_t)n * nin * cin;
+    const E *src = a2 + (size_t)n * nin * cin;
     if (STAGED) {
-        for (int i = tid * 4; i < nin * cin; i += 2048) *(f32x4 *)&s_a2[i] = *(const f32x4 *)&src[i];
+        for (int i = tid * 4; i < nin * cin; i += 2048) *(f32x4 *)&s_a2[i] = load4<E>(&src[i]);
         __syncthreads();
     }
-    const float *act = STAGED ? s_a2 : src;
+    // four channels of one input pixel: from the staged fp32 copy or straight from global memory
+    auto act4 = [&](size_t idx) -> f32x4 {
+        if constexpr (STAGED)
+            return *(const f32x4 *)&s_a2[idx];
+        else
+            return load4<E>(src + idx);
+    };
     const int grp = tid >> 4, sub = tid & 15;
     for (int ph = 0; ph < 4; ++ph) {
         const int py = ph >> 1, px = ph & 1;
@@ -74,10 +80,10 @@ __global__ __launch_bounds__(512) void gen_last_kernel(const float *__restrict__
                     const int iy1 = my + dy1, ix1 = mx + dx1;
                     const bool yok = (unsigned)iy1 < (unsigned)hin, xok = (unsigned)ix1 < (unsigned)hin;
                     const f32x4 z = 0.f;
-                    const f32x4 v00 = *(const f32x4 *)&act[(size_t)(my * hin + mx) * cin + c];
-                    const f32x4 v01 = xok ? *(const f32x4 *)&act[(size_t)(my * hin + ix1) * cin + c] : z;
-                    const f32x4 v10 = yok ? *(const f32x4 *)&act[(size_t)(iy1 * hin + mx) * cin + c] : z;
-                    const f32x4 v11 = (yok && xok) ? *(const f32x4 *)&act[(size_t)(iy1 * hin + ix1) * cin + c] : z;
+                    const f32x4 v00 = act4((size_t)(my * hin + mx) * cin + c);
+                    const f32x4 v01 = xok ? act4((size_t)(my * hin + ix1) * cin + c) : z;
+                    const f32x4 v10 = yok ? act4((size_t)(iy1 * hin + mx) * cin + c) : z;
+                    const f32x4 v11 = (yok && xok) ? act4((size_t)(iy1 * hin + ix1) * cin + c) : z;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         acc = fmaf(v00[k], w00[k], acc);
@@ -151,7 +157,8 @@ __global__ __launch_bounds__(512) void gen_last_kernel(const float *__restrict__
 using f32x4_t = __attribute__((ext_vector_type(4))) float;
 constexpr int GL_MAX_KSTEPS = 8;  // cin <= 128
 
-__global__ __launch_bounds__(512) void gen_last_mfma_kernel(const float *__restrict__ a2, const float *__restrict__ w5,
+template <typename E>
+__global__ __launch_bounds__(512) void gen_last_mfma_kernel(const E *__restrict__ a2, const float *__restrict__ w5,
                                                             float bias, int hin, int cin, float *__restrict__ img,
                                                             float *__restrict__ img01, const float *__restrict__ target,
                                                             float *__restrict__ mse, FastDiv div_c4, FastDiv div_side) {
@@ -165,12 +172,12 @@ __global__ __launch_bounds__(512) void gen_last_mfma_kernel(const float *__restr
     float *s_c = s_red + 32;                // [nblk * 16][16]
     float *s_a2 = s_c + nblk * 16 * 16;     // [nblk * 16][lda]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = blockIdx.x;
-    const float *src = a2 + (size_t)n * nin * cin;
+    const E *src = a2 + (size_t)n * nin * cin;
     const int c4 = cin / 4;
     for (int i = tid; i < nblk * 16 * c4; i += 512) {
         const int r = fdiv(i, div_c4), c = (i - r * c4) * 4;
         f32x4_t v = 0.f;
-        if (r < nin) v = *(const f32x4_t *)&src[(size_t)r * cin + c];
+        if (r < nin) v = load4<E>(&src[(size_t)r * cin + c]);
         *(f32x4_t *)&s_a2[r * lda + c] = v;
     }
     // W fragments: column l&15 is the kernel position ky*4+kx, stored as w5[position][channel]
@@ -255,9 +262,10 @@ __global__ __launch_bounds__(512) void gen_last_mfma_kernel(const float *__restr
 // the two 7-wide windows of a pair span 9 input pixels, read from the zero-padded image
 // in LDS as three wave-wide broadcast 16-byte reads per kernel row (row stride and window
 // start are multiples of 4 floats).  Conv rows of the band stay in LDS for the pooling.
+template <typename E>
 __global__ __launch_bounds__(512) void stem_kernel(const float *__restrict__ img01, const float *__restrict__ w,
                                                    const float *__restrict__ scale, const float *__restrict__ shift,
-                                                   int side, int ho, int hp, int band, int ps, float *__restrict__ out) {
+                                                   int side, int ho, int hp, int band, int ps, E *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int prows = side + 6;
     float *s_img = smem;                // [side+6][ps], zero border of 3 on the left/top
@@ -317,7 +325,7 @@ __global__ __launch_bounds__(512) void stem_kernel(const float *__restrict__ img
                 m = fmaxf(m, s_conv[((cy - cr0) * ho + cx) * 64 + c]);
             }
         }
-        out[(((size_t)n * hp + pr) * hp + pc) * 64 + c] = m;
+        out[(((size_t)n * hp + pr) * hp + pc) * 64 + c] = (E)m;
     }
 }
 
@@ -332,10 +340,11 @@ __global__ __launch_bounds__(512) void stem_kernel(const float *__restrict__ img
 // LDS, then the 3x3/2 max pool reads the conv image from LDS.
 constexpr int STEM_KSTEPS = 13;  // ceil(49 / 4)
 
+template <typename E>
 __global__ __launch_bounds__(512) void stem_mfma_kernel(const float *__restrict__ img01, const float *__restrict__ w,
                                                         const float *__restrict__ scale, const float *__restrict__ shift,
                                                         int side, int ho, int hp, int ps, FastDiv div_ho, FastDiv div_hp,
-                                                        float *__restrict__ out) {
+                                                        E *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int prows = side + 6, npx = ho * ho, nblk = (npx + 15) / 16;
     // n / d by multiply-shift (FastDiv): the chip has no integer divide
@@ -413,7 +422,7 @@ __global__ __launch_bounds__(512) void stem_mfma_kernel(const float *__restrict_
                 m = fmaxf(m, s_conv[(cy * ho + cx) * LDC + c]);
             }
         }
-        out[((size_t)n * hp * hp + pp) * 64 + c] = m;
+        out[((size_t)n * hp * hp + pp) * 64 + c] = (E)m;
     }
 }
 
@@ -424,14 +433,15 @@ __global__ __launch_bounds__(512) void stem_mfma_kernel(const float *__restrict_
 // One workgroup per image; per-class dot products reduced by wavefront shuffles.
 constexpr int MAX_CLASSES = 64;
 
-__global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ feat, int hw, int c, const float *__restrict__ fc_w,
+template <typename E>
+__global__ __launch_bounds__(256) void head_kernel(const E *__restrict__ feat, int hw, int c, const float *__restrict__ fc_w,
                                                    const float *__restrict__ fc_b, int n_class, float *__restrict__ logits,
                                                    float *__restrict__ fitness, int class_index, int mode, float threshold,
                                                    float eps, const float *__restrict__ mse, float w_ass, float w_rec) {
     __shared__ float s_part[4][MAX_CLASSES];
     __shared__ float s_logit[MAX_CLASSES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = blockIdx.x;
-    const float *src = feat + (size_t)n * hw * c;
+    const E *src = feat + (size_t)n * hw * c;
     // spatial max of this thread's channels: 4 consecutive channels per 1024-channel chunk (c <= 2048)
     float4 pooled[2];
 #pragma unroll
@@ -439,12 +449,13 @@ __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ fea
         const int ch = tid * 4 + u * 1024;
         pooled[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ch < c) {
-            float4 v = *(const float4 *)(src + ch);
+            f32x4 v = load4<E>(src + ch);
             for (int p = 1; p < hw; ++p) {
-                const float4 t = *(const float4 *)(src + (size_t)p * c + ch);
-                v.x = fmaxf(v.x, t.x); v.y = fmaxf(v.y, t.y); v.z = fmaxf(v.z, t.z); v.w = fmaxf(v.w, t.w);
+                const f32x4 t = load4<E>(src + (size_t)p * c + ch);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], t[q]);
             }
-            pooled[u] = v;
+            pooled[u] = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
     // four classes at a time: their eight weight loads are issued together (one class per trip
@@ -554,6 +565,7 @@ using namespace gdpso;
 
 // ============================================================================ generator
 struct gdpso_generator {
+    int dtype;  // DType of the activations between the layers and of the convolution weights
     int z_dim, kpad, features, k1, side;
     ConvLayer l1, l2;
     const float *w5;
@@ -575,9 +587,10 @@ GenLayout gen_layout(const gdpso_generator *g, int n, ConvLayer &l1, ConvLayer &
     plan_conv(l2, n, g->num_cus);
     GenLayout L;
     size_t off = 0;
-    L.zpad = off; off += align_up((size_t)n * g->kpad * 4);
-    L.a1 = off;   off += align_up((size_t)n * g->k1 * g->k1 * 2 * g->features * 4);
-    L.a2 = off;   off += align_up((size_t)n * 4 * g->k1 * g->k1 * g->features * 4);
+    const size_t es = dtype_size(g->dtype);
+    L.zpad = off; off += align_up((size_t)n * g->kpad * es);
+    L.a1 = off;   off += align_up((size_t)n * g->k1 * g->k1 * 2 * g->features * es);
+    L.a2 = off;   off += align_up((size_t)n * 4 * g->k1 * g->k1 * g->features * es);
     L.splitk = off; off += align_up(std::max(conv_splitk_bytes(l1, n), conv_splitk_bytes(l2, n)));
     L.total = off;
     return L;
@@ -586,13 +599,21 @@ GenLayout gen_layout(const gdpso_generator *g, int n, ConvLayer &l1, ConvLayer &
 
 extern "C" int gdpso_generator_create(gdpso_generator **out, int z_dim, int features_g, int first_kernel,
                                       const float *const *t, int n_tensors) {
+    return gdpso_generator_create_typed(out, z_dim, features_g, first_kernel, t, n_tensors, GDPSO_DTYPE_F32);
+}
+
+extern "C" int gdpso_generator_create_typed(gdpso_generator **out, int z_dim, int features_g, int first_kernel,
+                                            const float *const *t, int n_tensors, int dtype) {
     GDPSO_REQUIRE(out && t, "generator_create: null argument");
+    GDPSO_REQUIRE(dtype_ok(dtype), "generator_create: dtype must be GDPSO_DTYPE_F32, _BF16 or _F16");
+    GDPSO_REQUIRE(dtype == DT_F32 || features_g % 64 == 0, "generator_create: 16-bit types need features_g to be a multiple of 64");
     GDPSO_REQUIRE(n_tensors == 14, "generator_create: expected 14 tensors");
     GDPSO_REQUIRE(z_dim > 0 && features_g >= 32 && features_g % 32 == 0, "generator_create: features_g must be a multiple of 32");
     GDPSO_REQUIRE(first_kernel >= 1 && first_kernel * first_kernel * 2 * features_g % 64 == 0, "generator_create: bad first_kernel");
     auto g = new gdpso_generator();
+    g->dtype = dtype;
     g->z_dim = z_dim;
-    g->kpad = (z_dim + 31) / 32 * 32;
+    g->kpad = (z_dim + dtype_kquant(dtype) - 1) / dtype_kquant(dtype) * dtype_kquant(dtype);
     g->features = features_g;
     g->k1 = first_kernel;
     g->side = 4 * first_kernel;
@@ -618,13 +639,13 @@ extern "C" int gdpso_generator_create(gdpso_generator **out, int z_dim, int feat
                 sc[(size_t)p * c1 + co] = sc1[co];
                 sh[(size_t)p * c1 + co] = sh1[co];
             }
-        if ((rc = upload_conv(g->arena, g->l1, packed, sc, sh))) { delete g; return rc; }
+        if ((rc = upload_conv(g->arena, g->l1, packed, sc, sh, dtype))) { delete g; return rc; }
     }
     {
         std::vector<float> packed, sc, sh;
         make_convt_k4s2p1(g->l2, t[6], c1, c2, k, k, ACT_RELU, packed);
         fold_bn(c2, t[7], t[8], t[9], t[10], t[11], sc, sh);
-        if ((rc = upload_conv(g->arena, g->l2, packed, sc, sh))) { delete g; return rc; }
+        if ((rc = upload_conv(g->arena, g->l2, packed, sc, sh, dtype))) { delete g; return rc; }
     }
     {
         std::vector<float> w5((size_t)16 * c2);
@@ -637,9 +658,12 @@ extern "C" int gdpso_generator_create(gdpso_generator **out, int z_dim, int feat
         const char *e = getenv("GDPSO_GEN_LAST_MFMA");
         g->last_mfma = (e ? e[0] != '0' : true) && features_g % 16 == 0 && features_g <= 16 * GL_MAX_KSTEPS;
         g->last_mfma_lds_max = 64 * 1024;
-        if (g->last_mfma &&
-            hipFuncSetAttribute((const void *)gen_last_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) == hipSuccess)
-            g->last_mfma_lds_max = 152 * 1024;
+        if (g->last_mfma) {
+            hipError_t e2 = hipErrorUnknown;
+            GDPSO_WITH_DTYPE(dtype, e2 = hipFuncSetAttribute((const void *)gen_last_mfma_kernel<E>,
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+            if (e2 == hipSuccess) g->last_mfma_lds_max = 152 * 1024;
+        }
     }
     *out = g;
     return GDPSO_OK;
@@ -665,10 +689,11 @@ extern "C" int gdpso_generator_forward(const gdpso_generator *g, void *stream_, 
     const GenLayout L = gen_layout(g, n, l1, l2);
     if (workspace_bytes < L.total) return fail(GDPSO_ERR_WORKSPACE, "generator_forward: workspace too small");
     char *ws = (char *)workspace;
-    float *zpad = (float *)(ws + L.zpad), *a1 = (float *)(ws + L.a1), *a2 = (float *)(ws + L.a2);
+    void *zpad = ws + L.zpad, *a1 = ws + L.a1, *a2 = ws + L.a2;
     float *sk = (float *)(ws + L.splitk);
     const long ne = (long)n * g->kpad;
-    hipLaunchKernelGGL(latent_prep_kernel, dim3(ceil_div(ne, 256)), dim3(256), 0, stream, z, z_is_f64, n, g->z_dim, g->kpad, zpad);
+    GDPSO_WITH_DTYPE(g->dtype, hipLaunchKernelGGL(latent_prep_kernel<E>, dim3(ceil_div(ne, 256)), dim3(256), 0, stream, z, z_is_f64, n,
+                                                  g->z_dim, g->kpad, (E *)zpad));
     int rc;
     if ((rc = conv_splitk_prepare(stream, sk))) return rc;
     if ((rc = launch_conv(l1, stream, n, zpad, nullptr, a1, sk))) return rc;
@@ -679,12 +704,15 @@ extern "C" int gdpso_generator_forward(const gdpso_generator *g, void *stream_, 
     const int nblk = (hin * hin + 15) / 16;
     const size_t mfma_lds = base + ((size_t)nblk * 16 * 16 + (size_t)nblk * 16 * (g->features + 4)) * sizeof(float);
     if (g->last_mfma && mfma_lds <= g->last_mfma_lds_max)
-        hipLaunchKernelGGL(gen_last_mfma_kernel, dim3(n), dim3(512), mfma_lds, stream, a2, g->w5, g->b5, hin, g->features, img, img01, target, mse,
-                           fast_div_for((unsigned)(g->features / 4)), fast_div_for((unsigned)(2 * hin)));
+        GDPSO_WITH_DTYPE(g->dtype, hipLaunchKernelGGL(gen_last_mfma_kernel<E>, dim3(n), dim3(512), mfma_lds, stream, (const E *)a2, g->w5,
+                                                      g->b5, hin, g->features, img, img01, target, mse,
+                                                      fast_div_for((unsigned)(g->features / 4)), fast_div_for((unsigned)(2 * hin))));
     else if (staged <= 64 * 1024)
-        hipLaunchKernelGGL(gen_last_kernel<true>, dim3(n), dim3(512), staged, stream, a2, g->w5, g->b5, hin, g->features, img, img01, target, mse);
+        GDPSO_WITH_DTYPE(g->dtype, hipLaunchKernelGGL((gen_last_kernel<true, E>), dim3(n), dim3(512), staged, stream, (const E *)a2, g->w5,
+                                                      g->b5, hin, g->features, img, img01, target, mse));
     else
-        hipLaunchKernelGGL(gen_last_kernel<false>, dim3(n), dim3(512), base, stream, a2, g->w5, g->b5, hin, g->features, img, img01, target, mse);
+        GDPSO_WITH_DTYPE(g->dtype, hipLaunchKernelGGL((gen_last_kernel<false, E>), dim3(n), dim3(512), base, stream, (const E *)a2, g->w5,
+                                                      g->b5, hin, g->features, img, img01, target, mse));
     GDPSO_HIP(hipGetLastError());
     return GDPSO_OK;
 }
@@ -696,6 +724,7 @@ struct Bottleneck {
 };
 
 struct gdpso_assessor {
+    int dtype;  // DType of the feature maps and of the convolution weights
     int n_class, side, ho, hp, stem_band, stem_ps;
     const float *stem_w, *stem_scale, *stem_shift;
     std::vector<Bottleneck> blocks;
@@ -731,11 +760,12 @@ AssLayout ass_layout(const gdpso_assessor *a, int n) {
         }
     }
     size_t off = 0;
-    L.x = off; off += align_up(xy * 4);
-    L.y = off; off += align_up(xy * 4);
-    L.t1 = off; off += align_up(t1 * 4);
-    L.t2 = off; off += align_up(t2 * 4);
-    L.sc = off; off += align_up(sc * 4);
+    const size_t es = dtype_size(a->dtype);
+    L.x = off; off += align_up(xy * es);
+    L.y = off; off += align_up(xy * es);
+    L.t1 = off; off += align_up(t1 * es);
+    L.t2 = off; off += align_up(t2 * es);
+    L.sc = off; off += align_up(sc * es);
     L.splitk = off; off += align_up(sk);
     L.total = off;
     return L;
@@ -744,7 +774,13 @@ AssLayout ass_layout(const gdpso_assessor *a, int n) {
 
 extern "C" int gdpso_assessor_create_resnet(gdpso_assessor **out, const int depths[4], int n_class, int img_side,
                                             const float *const *t, int n_tensors) {
+    return gdpso_assessor_create_resnet_typed(out, depths, n_class, img_side, t, n_tensors, GDPSO_DTYPE_F32);
+}
+
+extern "C" int gdpso_assessor_create_resnet_typed(gdpso_assessor **out, const int depths[4], int n_class, int img_side,
+                                                  const float *const *t, int n_tensors, int dtype) {
     GDPSO_REQUIRE(out && depths && t, "assessor_create: null argument");
+    GDPSO_REQUIRE(dtype_ok(dtype), "assessor_create: dtype must be GDPSO_DTYPE_F32, _BF16 or _F16");
     GDPSO_REQUIRE(n_class >= 2 && n_class <= MAX_CLASSES, "assessor_create: n_class must be in [2, 64]");
     GDPSO_REQUIRE(img_side >= 8 && img_side <= 64, "assessor_create: img_side must be in [8, 64]");
     int expect = 5 + 2;
@@ -754,6 +790,7 @@ extern "C" int gdpso_assessor_create_resnet(gdpso_assessor **out, const int dept
     }
     GDPSO_REQUIRE(n_tensors == expect, "assessor_create: wrong number of tensors for these depths");
     auto a = new gdpso_assessor();
+    a->dtype = dtype;
     a->n_class = n_class;
     a->side = img_side;
     a->ho = (img_side + 6 - 7) / 2 + 1;
@@ -788,21 +825,21 @@ extern "C" int gdpso_assessor_create_resnet(gdpso_assessor **out, const int dept
             std::vector<float> packed, sc, sh;
             make_conv(blk.c1, t[ti], mid, cin, 1, 1, 1, 0, h, h, ACT_RELU, packed);
             fold_bn(mid, nullptr, t[ti + 1], t[ti + 2], t[ti + 3], t[ti + 4], sc, sh);
-            if ((rc = upload_conv(a->arena, blk.c1, packed, sc, sh))) { delete a; return rc; }
+            if ((rc = upload_conv(a->arena, blk.c1, packed, sc, sh, dtype))) { delete a; return rc; }
             make_conv(blk.c2, t[ti + 5], mid, mid, 3, 3, stride, 1, h, h, ACT_RELU, packed);
             fold_bn(mid, nullptr, t[ti + 6], t[ti + 7], t[ti + 8], t[ti + 9], sc, sh);
-            if ((rc = upload_conv(a->arena, blk.c2, packed, sc, sh))) { delete a; return rc; }
+            if ((rc = upload_conv(a->arena, blk.c2, packed, sc, sh, dtype))) { delete a; return rc; }
             const int h2 = blk.c2.hout;
             make_conv(blk.c3, t[ti + 10], mid * 4, mid, 1, 1, 1, 0, h2, h2, ACT_RELU, packed);  // ReLU after the residual add
             fold_bn(mid * 4, nullptr, t[ti + 11], t[ti + 12], t[ti + 13], t[ti + 14], sc, sh);
-            if ((rc = upload_conv(a->arena, blk.c3, packed, sc, sh))) { delete a; return rc; }
+            if ((rc = upload_conv(a->arena, blk.c3, packed, sc, sh, dtype))) { delete a; return rc; }
             ti += 15;
             blk.has_ds = (b == 0);
             a->flops += blk.c1.flops_nominal + blk.c2.flops_nominal + blk.c3.flops_nominal;
             if (blk.has_ds) {
                 make_conv(blk.ds, t[ti], mid * 4, cin, 1, 1, stride, 0, h, h, ACT_NONE, packed);
                 fold_bn(mid * 4, nullptr, t[ti + 1], t[ti + 2], t[ti + 3], t[ti + 4], sc, sh);
-                if ((rc = upload_conv(a->arena, blk.ds, packed, sc, sh))) { delete a; return rc; }
+                if ((rc = upload_conv(a->arena, blk.ds, packed, sc, sh, dtype))) { delete a; return rc; }
                 ti += 5;
                 a->flops += blk.ds.flops_nominal;
             }
@@ -842,8 +879,8 @@ extern "C" int gdpso_assessor_forward(const gdpso_assessor *a, void *stream_, in
     const AssLayout L = ass_layout(a, n);
     if (workspace_bytes < L.total) return fail(GDPSO_ERR_WORKSPACE, "assessor_forward: workspace too small");
     char *ws = (char *)workspace;
-    float *x = (float *)(ws + L.x), *y = (float *)(ws + L.y), *t1 = (float *)(ws + L.t1), *t2 = (float *)(ws + L.t2);
-    float *sc = (float *)(ws + L.sc), *sk = (float *)(ws + L.splitk);
+    void *x = ws + L.x, *y = ws + L.y, *t1 = ws + L.t1, *t2 = ws + L.t2, *sc = ws + L.sc;
+    float *sk = (float *)(ws + L.splitk);
     static const bool stem_mfma = [] {
         const char *e = getenv("GDPSO_STEM_MFMA");
         return e ? e[0] != '0' : true;
@@ -851,19 +888,20 @@ extern "C" int gdpso_assessor_forward(const gdpso_assessor *a, void *stream_, in
     const int mps = (a->side + 6 + 3) / 4 * 4;
     const size_t mfma_smem = ((size_t)(a->side + 6) * mps + (size_t)((a->ho * a->ho + 15) / 16 * 16) * 68) * sizeof(float);
     if (stem_mfma && mfma_smem <= 64 * 1024) {
-        hipLaunchKernelGGL(stem_mfma_kernel, dim3(n), dim3(512), mfma_smem, stream, img01, a->stem_w, a->stem_scale, a->stem_shift,
-                           a->side, a->ho, a->hp, mps, fast_div_for((unsigned)a->ho), fast_div_for((unsigned)a->hp), x);
+        GDPSO_WITH_DTYPE(a->dtype, hipLaunchKernelGGL(stem_mfma_kernel<E>, dim3(n), dim3(512), mfma_smem, stream, img01, a->stem_w,
+                                                      a->stem_scale, a->stem_shift, a->side, a->ho, a->hp, mps,
+                                                      fast_div_for((unsigned)a->ho), fast_div_for((unsigned)a->hp), (E *)x));
     } else {
         const int rows = 2 * a->stem_band + 1;
         const size_t smem = ((size_t)(a->side + 6) * a->stem_ps + (size_t)rows * a->ho * 64) * sizeof(float);
         dim3 grid(n, ceil_div(a->hp, a->stem_band));
-        hipLaunchKernelGGL(stem_kernel, grid, dim3(512), smem, stream, img01, a->stem_w, a->stem_scale, a->stem_shift, a->side,
-                           a->ho, a->hp, a->stem_band, a->stem_ps, x);
+        GDPSO_WITH_DTYPE(a->dtype, hipLaunchKernelGGL(stem_kernel<E>, grid, dim3(512), smem, stream, img01, a->stem_w, a->stem_scale,
+                                                      a->stem_shift, a->side, a->ho, a->hp, a->stem_band, a->stem_ps, (E *)x));
     }
     int rc;
     if ((rc = conv_splitk_prepare(stream, sk))) return rc;
     for (const Bottleneck &b : L.blocks) {
-        const float *res = x;
+        const void *res = x;
         if (b.has_ds) {  // identity_downsample and conv1 read the same input: one launch when their shapes allow
             if ((rc = launch_conv_pair(b.ds, b.c1, stream, n, x, sc, t1, sk))) return rc;
             res = sc;
@@ -873,8 +911,9 @@ extern "C" int gdpso_assessor_forward(const gdpso_assessor *a, void *stream_, in
         if ((rc = launch_conv_then_1x1(b.c2, b.c3, stream, n, t1, t2, res, y, sk))) return rc;
         std::swap(x, y);
     }
-    hipLaunchKernelGGL(head_kernel, dim3(n), dim3(256), 0, stream, x, a->feat_hw, a->feat_c, a->fc_w, a->fc_b, a->n_class, logits,
-                       fitness, class_index, mode, threshold, eps, mse, w_ass, w_rec);
+    GDPSO_WITH_DTYPE(a->dtype, hipLaunchKernelGGL(head_kernel<E>, dim3(n), dim3(256), 0, stream, (const E *)x, a->feat_hw, a->feat_c,
+                                                  a->fc_w, a->fc_b, a->n_class, logits, fitness, class_index, mode, threshold, eps, mse,
+                                                  w_ass, w_rec));
     GDPSO_HIP(hipGetLastError());
     return GDPSO_OK;
 }

@@ -233,11 +233,26 @@ void make_convt_k4s2p1(ConvLayer &L, const float *w, int cin, int cout, int hin,
     sort_phases_heaviest_first(L);
 }
 
+uint16_t f32_to_bf16_bits(float v) {
+    uint32_t u;
+    std::memcpy(&u, &v, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);  // NaN stays a (quiet) NaN
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+uint16_t f32_to_f16_bits(float v) {
+    const _Float16 h = (_Float16)v;  // the compiler's conversion rounds to nearest even
+    uint16_t b;
+    std::memcpy(&b, &h, 2);
+    return b;
+}
+
 // Device table of a layer: per phase PHASE_HDR ints {ntaps, off_y, off_x, wt_offset, hm, wm,
 // in_y0, in_x0, wstride, mul(hm * wm), mul(wm), shift(hm * wm) | shift(wm) << 8} (mul / shift: FastDiv) followed by MAX_TAPS packed taps (dy & 0xff) | (dx & 0xff) << 8
 // | wtap << 16.
 int upload_conv(DeviceArena &arena, ConvLayer &L, const std::vector<float> &packed,
-                const std::vector<float> &scale, const std::vector<float> &shift) {
+                const std::vector<float> &scale, const std::vector<float> &shift, int dtype) {
+    L.dtype = dtype;
     std::vector<int> table((size_t)L.nphase * (PHASE_HDR + MAX_TAPS), 0);
     for (int p = 0; p < L.nphase; ++p) {
         const ConvPhase &P = L.phase[p];
@@ -259,7 +274,13 @@ int upload_conv(DeviceArena &arena, ConvLayer &L, const std::vector<float> &pack
             t[PHASE_HDR + k] = ((int)P.dy[k] & 0xff) | (((int)P.dx[k] & 0xff) << 8) | ((int)P.wtap[k] << 16);
     }
     int rc;
-    if ((rc = arena.upload(packed, &L.wt))) return rc;
+    if (dtype == DT_F32) {
+        if ((rc = arena.upload(packed.data(), packed.size() * sizeof(float), &L.wt))) return rc;
+    } else {
+        std::vector<uint16_t> half(packed.size());
+        for (size_t i = 0; i < packed.size(); ++i) half[i] = dtype == DT_BF16 ? f32_to_bf16_bits(packed[i]) : f32_to_f16_bits(packed[i]);
+        if ((rc = arena.upload(half.data(), half.size() * sizeof(uint16_t), &L.wt))) return rc;
+    }
     if ((rc = arena.upload(scale, &L.scale))) return rc;
     if ((rc = arena.upload(shift, &L.shift))) return rc;
     if ((rc = arena.upload(table.data(), table.size() * sizeof(int), (const void **)&L.table))) return rc;

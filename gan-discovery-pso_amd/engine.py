@@ -105,6 +105,16 @@ class _Handle:
             pass
 
 
+def _dtype_code(dtype) -> int:
+    """"f32" (the reference's precision) | "bf16" | "f16": storage and matrix-instruction input type of
+    a packed network (accumulation and epilogues are fp32 either way)."""
+    if isinstance(dtype, torch.dtype):
+        dtype = {torch.float32: "f32", torch.bfloat16: "bf16", torch.float16: "f16"}.get(dtype, str(dtype))
+    if dtype not in _lib.DTYPES:
+        raise ValueError(f"dtype must be one of {sorted(_lib.DTYPES)}, got {dtype!r}")
+    return _lib.DTYPES[dtype]
+
+
 def _device_guard(device):
     device = torch.device(device)
     if device.type != "cuda":
@@ -116,14 +126,15 @@ class PackedGenerator(_Handle):
     """Generator weights repacked on the device (gdpso_generator_create)."""
     _destroy = "gdpso_generator_destroy"
 
-    def __init__(self, model, device, prefix="gen"):
+    def __init__(self, model, device, prefix="gen", dtype="f32"):
         super().__init__()
         self.device = _device_guard(device)
+        self.dtype = dtype
         tensors, self.meta = generator_tensors(_state_dict_of(model), prefix)
         arr, keep = _lib.host_float_pointers(tensors)
         with torch.cuda.device(self.device):
-            check(_lib.lib().gdpso_generator_create(C.byref(self.h), self.meta["z_dim"], self.meta["features_g"],
-                                                    self.meta["first_kernel"], arr, len(keep)))
+            check(_lib.lib().gdpso_generator_create_typed(C.byref(self.h), self.meta["z_dim"], self.meta["features_g"],
+                                                          self.meta["first_kernel"], arr, len(keep), _dtype_code(dtype)))
         self.z_dim = self.meta["z_dim"]
         self.side = _lib.lib().gdpso_generator_image_side(self.h)
         # nominal MACs x2: ConvT(z->2F,k) + ConvT(2F->F,k4s2: 4 taps/output) + ConvT(F->1)
@@ -153,14 +164,16 @@ class PackedAssessor(_Handle):
     """ResNet assessor weights repacked on the device (gdpso_assessor_create_resnet)."""
     _destroy = "gdpso_assessor_destroy"
 
-    def __init__(self, model, device, img_side=28):
+    def __init__(self, model, device, img_side=28, dtype="f32"):
         super().__init__()
         self.device = _device_guard(device)
+        self.dtype = dtype
         tensors, self.meta = resnet_tensors(_state_dict_of(model))
         arr, keep = _lib.host_float_pointers(tensors)
         depths = (C.c_int * 4)(*self.meta["depths"])
         with torch.cuda.device(self.device):
-            check(_lib.lib().gdpso_assessor_create_resnet(C.byref(self.h), depths, self.meta["n_class"], img_side, arr, len(keep)))
+            check(_lib.lib().gdpso_assessor_create_resnet_typed(C.byref(self.h), depths, self.meta["n_class"], img_side, arr,
+                                                                len(keep), _dtype_code(dtype)))
         self.n_class = self.meta["n_class"]
         self.side = img_side
         self.flops_per_image = _lib.lib().gdpso_assessor_flops_per_image(self.h)

@@ -25,6 +25,9 @@ class Discovery:
         if iid_classes is not None:
             self.class_to_idx = {c: i for i, c in enumerate(sorted(iid_classes))}
             self.idx_to_class = {i: c for c, i in self.class_to_idx.items()}
+        # knob that does not exist in the reference (which is fp32 throughout): "bf16" / "f16" keep the
+        # networks' activations and convolution weights in that type on the device
+        self.compute_dtype = "f32"
         self._evaluator = None
         self._evaluator_key = None
 
@@ -46,10 +49,10 @@ class Discovery:
     def evaluator(self) -> engine.Evaluator:
         """The packed device copy of the two networks; rebuilt when either model's weights have
         changed since it was packed (the reference calls the live modules every time)."""
-        key = (self._model_key(self.model_gan), self._model_key(self.model_cnn), str(self.device))
+        key = (self._model_key(self.model_gan), self._model_key(self.model_cnn), str(self.device), self.compute_dtype)
         if self._evaluator is None or self._evaluator_key != key:
-            gen = engine.PackedGenerator(self.model_gan, self.device)
-            ass = engine.PackedAssessor(self.model_cnn, self.device, img_side=gen.side)
+            gen = engine.PackedGenerator(self.model_gan, self.device, dtype=self.compute_dtype)
+            ass = engine.PackedAssessor(self.model_cnn, self.device, img_side=gen.side, dtype=self.compute_dtype)
             self._evaluator = engine.Evaluator(gen, ass)
             self._evaluator_key = key
         return self._evaluator

@@ -37,6 +37,15 @@ extern "C" {
 #define GDPSO_MODE_IN_TRAINING 0  /* fitness = min(p + thr, 1) + eps        */
 #define GDPSO_MODE_OUT_TRAINING 1 /* fitness = (1 - min(p + thr, 1)) + eps  */
 
+/* Storage / matrix-core input type of a network handle: fp32 everywhere (the reference's
+ * precision), or activations and convolution weights kept as bf16 / fp16 and multiplied by the
+ * 16-bit matrix instructions, with fp32 accumulation and an fp32 epilogue (BatchNorm scale / shift,
+ * residual add, activation).  The reference has no reduced-precision mode; images, logits and
+ * fitness values cross the ABI as fp32 whatever the handle's type. */
+#define GDPSO_DTYPE_F32 0
+#define GDPSO_DTYPE_BF16 1
+#define GDPSO_DTYPE_F16 2
+
 int gdpso_abi_version(void);
 const char *gdpso_last_error(void);
 /* sizeof(gdpso_swarm) for which = 0, sizeof(gdpso_run) for which = 1, else 0: lets a foreign
@@ -61,6 +70,13 @@ typedef struct gdpso_generator gdpso_generator;
  * first_kernel k is 7 in the reference (28x28 images); output side = 4k. */
 int gdpso_generator_create(gdpso_generator **out, int z_dim, int features_g, int first_kernel,
                            const float *const *tensors, int n_tensors);
+/* The same with the element type of the activations between the layers and of the ConvTranspose
+ * weights chosen by `dtype` (GDPSO_DTYPE_*; gdpso_generator_create is the GDPSO_DTYPE_F32 case).
+ * The last layer (F -> 1 channel), tanh and the rescale are computed in fp32 either way.  The
+ * 16-bit types need features_g to be a multiple of 64.  No counterpart in the reference (which is
+ * fp32 throughout): results differ from it by the rounding of the stored activations. */
+int gdpso_generator_create_typed(gdpso_generator **out, int z_dim, int features_g, int first_kernel,
+                                 const float *const *tensors, int n_tensors, int dtype);
 void gdpso_generator_destroy(gdpso_generator *g);
 int gdpso_generator_image_side(const gdpso_generator *g);
 size_t gdpso_generator_workspace_bytes(const gdpso_generator *g, int n);
@@ -93,6 +109,11 @@ typedef struct gdpso_assessor gdpso_assessor;
  * img_side: input image side the plan is specialised for (28, 64, ...). */
 int gdpso_assessor_create_resnet(gdpso_assessor **out, const int depths[4], int n_class, int img_side,
                                  const float *const *tensors, int n_tensors);
+/* The same with feature maps and convolution weights stored as `dtype` (GDPSO_DTYPE_*); the stem
+ * (1 input channel), BatchNorm scale / shift, residual adds, pooling, classifier and softmax stay
+ * fp32.  gdpso_assessor_create_resnet is the GDPSO_DTYPE_F32 case. */
+int gdpso_assessor_create_resnet_typed(gdpso_assessor **out, const int depths[4], int n_class, int img_side,
+                                       const float *const *tensors, int n_tensors, int dtype);
 void gdpso_assessor_destroy(gdpso_assessor *a);
 size_t gdpso_assessor_workspace_bytes(const gdpso_assessor *a, int n);
 int gdpso_assessor_n_class(const gdpso_assessor *a);
@@ -311,6 +332,13 @@ int gdpso_conv_probe(int n_images, int hin, int cin, int cout, int ksize, int st
 int gdpso_conv_layer_run(int n_images, int hin, int cin, int cout, int ksize, int stride, int pad, int transposed,
                          int act, int tile, int splits, const float *weight, const float *scale, const float *shift,
                          const float *in, const float *res, float *out, int *tile_used, int *splits_used);
+
+/* The same with the layer's activations and weights stored as `dtype` (GDPSO_DTYPE_*): in / res are
+ * rounded to that type on the way in, the output is widened back to fp32 (cin a multiple of 64 for
+ * the 16-bit types). */
+int gdpso_conv_layer_run_typed(int n_images, int hin, int cin, int cout, int ksize, int stride, int pad, int transposed,
+                               int act, int tile, int splits, const float *weight, const float *scale, const float *shift,
+                               const float *in, const float *res, float *out, int *tile_used, int *splits_used, int dtype);
 
 #ifdef __cplusplus
 }
