@@ -92,6 +92,10 @@ _PROTOTYPES = {
     "gdpso_conv_probe": (c_int, [c_int] * 11 + [C.POINTER(c_double), C.POINTER(c_int), C.POINTER(c_int)]),
     "gdpso_conv_layer_run": (c_int, [c_int] * 11 + [c_void_p] * 6 + [C.POINTER(c_int), C.POINTER(c_int)]),
     "gdpso_conv_layer_run_typed": (c_int, [c_int] * 11 + [c_void_p] * 6 + [C.POINTER(c_int), C.POINTER(c_int), c_int]),
+    "gdpso_assessor_forward_classes": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
+                                               c_float, c_void_p, c_float, c_float, c_void_p, c_size_t]),
+    "gdpso_swarm_iterate_multi": (c_int, [C.POINTER(SwarmDesc), C.POINTER(RunDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_int, c_int]),
     "gdpso_swarm_iterate": (c_int, [C.POINTER(SwarmDesc), c_void_p, c_void_p, C.POINTER(RunDesc), c_void_p, c_int, c_int]),
 }
 

@@ -436,7 +436,8 @@ constexpr int MAX_CLASSES = 64;
 template <typename E>
 __global__ __launch_bounds__(256) void head_kernel(const E *__restrict__ feat, int hw, int c, const float *__restrict__ fc_w,
                                                    const float *__restrict__ fc_b, int n_class, float *__restrict__ logits,
-                                                   float *__restrict__ fitness, int class_index, int mode, float threshold,
+                                                   float *__restrict__ fitness, int class_index,
+                                                   const int *__restrict__ class_per_image, int mode, float threshold,
                                                    float eps, const float *__restrict__ mse, float w_ass, float w_rec) {
     __shared__ float s_part[4][MAX_CLASSES];
     __shared__ float s_logit[MAX_CLASSES];
@@ -500,7 +501,8 @@ __global__ __launch_bounds__(256) void head_kernel(const E *__restrict__ feat, i
         for (int k = 0; k < n_class; ++k) m = fmaxf(m, s_logit[k]);
         float sum = 0.f;
         for (int k = 0; k < n_class; ++k) sum += expf(s_logit[k] - m);
-        const int sel = n_class > 2 ? class_index : 1;
+        // several swarms in one batch: every image carries the class its swarm is after
+        const int sel = n_class > 2 ? (class_per_image ? class_per_image[n] : class_index) : 1;
         const float p = expf(s_logit[sel] - m) / sum;
         const float pc = fminf(p + threshold, 1.0f);
         float f = (mode == GDPSO_MODE_IN_TRAINING ? pc : (1.0f - pc)) + eps;
@@ -867,14 +869,16 @@ extern "C" size_t gdpso_assessor_workspace_bytes(const gdpso_assessor *a, int n)
     return ass_layout(a, n).total;
 }
 
-extern "C" int gdpso_assessor_forward(const gdpso_assessor *a, void *stream_, int n, const float *img01, float *logits,
-                                      float *fitness, int class_index, int mode, float threshold, float eps,
-                                      const float *mse, float w_ass, float w_rec, void *workspace, size_t workspace_bytes) {
+static int assessor_forward_impl(const gdpso_assessor *a, void *stream_, int n, const float *img01, float *logits,
+                                 float *fitness, int class_index, const int *class_per_image, int mode, float threshold,
+                                 float eps, const float *mse, float w_ass, float w_rec, void *workspace,
+                                 size_t workspace_bytes) {
     GDPSO_REQUIRE(a && img01 && workspace, "assessor_forward: null argument");
     GDPSO_REQUIRE(n > 0, "assessor_forward: n must be positive");
     GDPSO_REQUIRE(logits || fitness, "assessor_forward: nothing to compute");
     GDPSO_REQUIRE(mode == GDPSO_MODE_IN_TRAINING || mode == GDPSO_MODE_OUT_TRAINING, "assessor_forward: unknown fitness mode");
-    GDPSO_REQUIRE(!fitness || a->n_class == 2 || (class_index >= 0 && class_index < a->n_class), "assessor_forward: class_index out of range");
+    GDPSO_REQUIRE(!fitness || a->n_class == 2 || class_per_image || (class_index >= 0 && class_index < a->n_class),
+                  "assessor_forward: class_index out of range");
     hipStream_t stream = (hipStream_t)stream_;
     const AssLayout L = ass_layout(a, n);
     if (workspace_bytes < L.total) return fail(GDPSO_ERR_WORKSPACE, "assessor_forward: workspace too small");
@@ -912,10 +916,26 @@ extern "C" int gdpso_assessor_forward(const gdpso_assessor *a, void *stream_, in
         std::swap(x, y);
     }
     GDPSO_WITH_DTYPE(a->dtype, hipLaunchKernelGGL(head_kernel<E>, dim3(n), dim3(256), 0, stream, (const E *)x, a->feat_hw, a->feat_c,
-                                                  a->fc_w, a->fc_b, a->n_class, logits, fitness, class_index, mode, threshold, eps, mse,
-                                                  w_ass, w_rec));
+                                                  a->fc_w, a->fc_b, a->n_class, logits, fitness, class_index, class_per_image, mode,
+                                                  threshold, eps, mse, w_ass, w_rec));
     GDPSO_HIP(hipGetLastError());
     return GDPSO_OK;
+}
+
+extern "C" int gdpso_assessor_forward(const gdpso_assessor *a, void *stream, int n, const float *img01, float *logits,
+                                      float *fitness, int class_index, int mode, float threshold, float eps,
+                                      const float *mse, float w_ass, float w_rec, void *workspace, size_t workspace_bytes) {
+    return assessor_forward_impl(a, stream, n, img01, logits, fitness, class_index, nullptr, mode, threshold, eps, mse, w_ass, w_rec,
+                                 workspace, workspace_bytes);
+}
+
+extern "C" int gdpso_assessor_forward_classes(const gdpso_assessor *a, void *stream, int n, const float *img01, float *logits,
+                                              float *fitness, const int *class_per_image, int mode, float threshold, float eps,
+                                              const float *mse, float w_ass, float w_rec, void *workspace,
+                                              size_t workspace_bytes) {
+    GDPSO_REQUIRE(class_per_image, "assessor_forward_classes: null class table");
+    return assessor_forward_impl(a, stream, n, img01, logits, fitness, 0, class_per_image, mode, threshold, eps, mse, w_ass, w_rec,
+                                 workspace, workspace_bytes);
 }
 
 // ============================================================================== encoder

@@ -6,6 +6,9 @@
 // reference's evaluation order, so positions and velocities are bit-identical to numpy's
 // for identical fitness decisions.  These kernels are HBM/latency bound (a few hundred
 // bytes per particle): elements are mapped to consecutive lanes for coalesced access.
+#include <algorithm>
+#include <cstring>
+
 #include "common.h"
 
 namespace gdpso {
@@ -301,14 +304,11 @@ __device__ __forceinline__ void small_local_phase(const gdpso_swarm &s, int rank
     for (int k = tid; k < s.d; k += SMALL_THREADS) rec[2 + k] = have ? s.pbest_pos[(size_t)(r.idx - s.first_index) * s.d + k] : 0.0;
 }
 
-__global__ __launch_bounds__(SMALL_THREADS) void swarm_step_small_kernel(gdpso_swarm s, int iteration, int schedule_inertia,
-                                                                         int early_stopping, double tolerance, double w_cogn,
-                                                                         double w_soci, const double *__restrict__ rnd,
-                                                                         uint64_t seed, int f32_terms) {
-    __shared__ unsigned char s_better[SMALL_MAX_N];
-    __shared__ BestRec s_best[SMALL_THREADS / 64];
-    __shared__ int s_take;
-    if (!running(s.ctrl, iteration)) return;
+// One whole PSO step of one swarm by one workgroup (every thread of the workgroup calls it).
+__device__ __forceinline__ void small_step(const gdpso_swarm &s, int iteration, int schedule_inertia, int early_stopping,
+                                           double tolerance, double w_cogn, double w_soci, const double *__restrict__ rnd,
+                                           uint64_t seed, int f32_terms, unsigned char *s_better, BestRec *s_best, int *s_take_p) {
+    int &s_take = *s_take_p;
     const int tid = threadIdx.x;
     small_local_phase(s, 0, s_better, s_best);
     const double *rec = s.cand;
@@ -325,6 +325,49 @@ __global__ __launch_bounds__(SMALL_THREADS) void swarm_step_small_kernel(gdpso_s
     const long nd = (long)s.n * s.d;
     const double w = s.ctrl[GDPSO_CTRL_W];
     for (long e = tid; e < nd; e += SMALL_THREADS) move_element(s, iteration, e, w, w_cogn, w_soci, rnd, seed, f32_terms);
+}
+
+__global__ __launch_bounds__(SMALL_THREADS) void swarm_step_small_kernel(gdpso_swarm s, int iteration, int schedule_inertia,
+                                                                         int early_stopping, double tolerance, double w_cogn,
+                                                                         double w_soci, const double *__restrict__ rnd,
+                                                                         uint64_t seed, int f32_terms) {
+    __shared__ unsigned char s_better[SMALL_MAX_N];
+    __shared__ BestRec s_best[SMALL_THREADS / 64];
+    __shared__ int s_take;
+    if (!running(s.ctrl, iteration)) return;
+    small_step(s, iteration, schedule_inertia, early_stopping, tolerance, w_cogn, w_soci, rnd, seed, f32_terms, s_better, s_best,
+               &s_take);
+}
+
+// Several independent swarms that share one evaluation batch (the reference walks its classes one
+// after the other, src/training/pso_discovery.py:174-218; each has its own global best, inertia,
+// draws and stopping state): workgroup b steps swarm b.  Descriptors travel as kernel arguments.
+constexpr int MULTI_MAX = 8;  // swarms per launch (more are stepped by further launches)
+struct SwarmBatch {
+    gdpso_swarm s[MULTI_MAX];
+    const double *rnd[MULTI_MAX];  // this iteration's (r1, r2) rows, or null (device RNG)
+    unsigned long long seed[MULTI_MAX];
+    double w_cogn[MULTI_MAX], w_soci[MULTI_MAX], tolerance[MULTI_MAX];
+    int schedule_inertia[MULTI_MAX], early_stopping[MULTI_MAX], f32_terms[MULTI_MAX];
+    int dist_tile[MULTI_MAX], dist_tiles[MULTI_MAX];  // mean-distance tiling of each swarm
+    double *dist_partial[MULTI_MAX];
+};
+static_assert(sizeof(SwarmBatch) <= 3072, "kernel arguments are limited to 4 KiB");
+
+// a swarm takes part in `iteration` while it has not stopped and the iteration is within its own budget
+__device__ __forceinline__ bool running_multi(const gdpso_swarm &s, int iteration) {
+    return iteration <= s.max_iter && running(s.ctrl, iteration);
+}
+
+__global__ __launch_bounds__(SMALL_THREADS) void swarm_step_small_multi_kernel(SwarmBatch b, int iteration) {
+    __shared__ unsigned char s_better[SMALL_MAX_N];
+    __shared__ BestRec s_best[SMALL_THREADS / 64];
+    __shared__ int s_take;
+    const int k = blockIdx.x;
+    const gdpso_swarm &s = b.s[k];
+    if (!running_multi(s, iteration)) return;
+    small_step(s, iteration, b.schedule_inertia[k], b.early_stopping[k], b.tolerance[k], b.w_cogn[k], b.w_soci[k], b.rnd[k],
+               b.seed[k], b.f32_terms[k], s_better, s_best, &s_take);
 }
 
 // The local half alone, for the sharded loop (the exchange of the candidate records follows it).
@@ -352,13 +395,10 @@ static int dist_tile_side(int d, int n) {
     }
     return dt;
 }
-__global__ __launch_bounds__(256) void pair_dist_kernel(const double *__restrict__ pos, int n, int d, int DT, int tiles,
-                                                        const double *ctrl, int iteration, double *__restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) double sd[];  // [2][DT][d]
-    __shared__ double s_sum[4];
-    if (!running(ctrl, iteration)) return;
+__device__ __forceinline__ void pair_dist_tile(const double *__restrict__ pos, int n, int d, int DT, int tiles, int block,
+                                                double *__restrict__ partial, double *sd, double *s_sum) {
     // linear block id -> (ti <= tj) upper-triangular tile
-    int b = blockIdx.x, ti = 0;
+    int b = block, ti = 0;
     while (b >= tiles - ti) {
         b -= tiles - ti;
         ++ti;
@@ -389,13 +429,30 @@ __global__ __launch_bounds__(256) void pair_dist_kernel(const double *__restrict
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     if ((tid & 63) == 0) s_sum[tid >> 6] = sum;
     __syncthreads();
-    if (tid == 0) partial[blockIdx.x] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+    if (tid == 0) partial[block] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
 }
 
-__global__ __launch_bounds__(256) void pair_dist_finish_kernel(const double *__restrict__ partial, int n_partial, int n,
-                                                               const double *ctrl, int iteration, double *__restrict__ out) {
+__global__ __launch_bounds__(256) void pair_dist_kernel(const double *__restrict__ pos, int n, int d, int DT, int tiles,
+                                                        const double *ctrl, int iteration, double *__restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) double sd[];  // [2][DT][d]
     __shared__ double s_sum[4];
     if (!running(ctrl, iteration)) return;
+    pair_dist_tile(pos, n, d, DT, tiles, blockIdx.x, partial, sd, s_sum);
+}
+
+// blockIdx.y = swarm of the batch, blockIdx.x = its tile (surplus blocks of smaller swarms exit)
+__global__ __launch_bounds__(256) void pair_dist_multi_kernel(SwarmBatch b, int iteration) {
+    extern __shared__ __attribute__((aligned(16))) double sd[];
+    __shared__ double s_sum[4];
+    const int k = blockIdx.y;
+    const gdpso_swarm &s = b.s[k];
+    const int tiles = b.dist_tiles[k];
+    if (!s.mean_dist || s.n < 2 || (int)blockIdx.x >= tiles * (tiles + 1) / 2 || !running_multi(s, iteration)) return;
+    pair_dist_tile(s.pos, s.n, s.d, b.dist_tile[k], tiles, blockIdx.x, b.dist_partial[k], sd, s_sum);
+}
+
+__device__ __forceinline__ void pair_dist_finish(const double *__restrict__ partial, int n_partial, int n, int iteration,
+                                                 double *__restrict__ out, double *s_sum) {
     const int tid = threadIdx.x;
     double sum = 0.0;
     for (int i = tid; i < n_partial; i += 256) sum += partial[i];
@@ -404,6 +461,22 @@ __global__ __launch_bounds__(256) void pair_dist_finish_kernel(const double *__r
     if ((tid & 63) == 0) s_sum[tid >> 6] = sum;
     __syncthreads();
     if (tid == 0) out[iteration - 1] = ((s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3])) / (0.5 * (double)n * (double)(n - 1));
+}
+
+__global__ __launch_bounds__(256) void pair_dist_finish_kernel(const double *__restrict__ partial, int n_partial, int n,
+                                                               const double *ctrl, int iteration, double *__restrict__ out) {
+    __shared__ double s_sum[4];
+    if (!running(ctrl, iteration)) return;
+    pair_dist_finish(partial, n_partial, n, iteration, out, s_sum);
+}
+
+__global__ __launch_bounds__(256) void pair_dist_finish_multi_kernel(SwarmBatch b, int iteration) {
+    __shared__ double s_sum[4];
+    const int k = blockIdx.x;
+    const gdpso_swarm &s = b.s[k];
+    if (!s.mean_dist || s.n < 2 || !running_multi(s, iteration)) return;
+    const int tiles = b.dist_tiles[k];
+    pair_dist_finish(b.dist_partial[k], tiles * (tiles + 1) / 2, s.n, iteration, s.mean_dist, s_sum);
 }
 
 static int check_swarm(const gdpso_swarm *s) {
@@ -533,6 +606,102 @@ extern "C" int gdpso_swarm_iterate(const gdpso_swarm *s, const gdpso_generator *
         }
         if (r->diagnostics && s->mean_dist && s->n >= 2)
             if ((rc = gdpso_swarm_mean_distance(s, stream, i, s->pos, s->n))) return rc;
+    }
+    return GDPSO_OK;
+}
+
+// Several independent swarms through ONE generator + assessor batch per iteration.
+extern "C" int gdpso_swarm_iterate_multi(const gdpso_swarm *swarms, const gdpso_run *runs, int n_swarms, const gdpso_generator *g,
+                                         const gdpso_assessor *a, const int *class_per_image, void *stream, int first_iteration,
+                                         int n_iterations) {
+    GDPSO_REQUIRE(swarms && runs && g && a && n_swarms >= 1, "swarm_iterate_multi: null argument");
+    GDPSO_REQUIRE(first_iteration >= 1 && n_iterations >= 0, "swarm_iterate_multi: bad iteration range");
+    long total = 0;
+    int rc;
+    for (int k = 0; k < n_swarms; ++k) {
+        const gdpso_swarm &s = swarms[k];
+        if ((rc = check_swarm(&s))) return rc;
+        GDPSO_REQUIRE(s.n_ranks == 1, "swarm_iterate_multi: single-process loop");
+        GDPSO_REQUIRE(s.d == swarms[0].d, "swarm_iterate_multi: every swarm needs the same dim_space");
+        // one evaluation batch: positions and fitness values of the swarms lie back to back
+        GDPSO_REQUIRE(s.pos == swarms[0].pos + total * s.d && s.fitness == swarms[0].fitness + total,
+                      "swarm_iterate_multi: pos / fitness of the swarms must be consecutive slices of one buffer");
+        GDPSO_REQUIRE(!runs[k].target && runs[k].mode == runs[0].mode && runs[k].threshold == runs[0].threshold &&
+                          runs[k].eps == runs[0].eps,
+                      "swarm_iterate_multi: the swarms share mode, threshold and eps; the inverter variant is not batched");
+        GDPSO_REQUIRE(gdpso_swarm_scratch_bytes(s.n) <= s.scratch_bytes, "swarm_iterate_multi: scratch too small");
+        total += s.n;
+    }
+    GDPSO_REQUIRE(total < (1L << 31), "swarm_iterate_multi: too many particles");
+    const gdpso_run &r0 = runs[0];
+    GDPSO_REQUIRE(r0.img01 && r0.workspace, "swarm_iterate_multi: runs[0] carries the shared image and workspace buffers");
+    GDPSO_REQUIRE(n_swarms == 1 || class_per_image || gdpso_assessor_n_class(a) == 2,
+                  "swarm_iterate_multi: a per-image class table is needed when the swarms are after different classes");
+    for (int i = first_iteration; i < first_iteration + n_iterations; ++i) {
+        bool any = false;
+        for (int k = 0; k < n_swarms; ++k) any |= i <= swarms[k].max_iter;
+        if (!any) break;
+        if ((rc = gdpso_generator_forward(g, stream, (int)total, swarms[0].pos, 1, r0.img, r0.img01, nullptr, nullptr, r0.workspace,
+                                          r0.workspace_bytes)))
+            return rc;
+        if (class_per_image)
+            rc = gdpso_assessor_forward_classes(a, stream, (int)total, r0.img01, nullptr, swarms[0].fitness, class_per_image, r0.mode,
+                                                r0.threshold, r0.eps, nullptr, r0.w_ass, r0.w_rec, r0.workspace, r0.workspace_bytes);
+        else
+            rc = gdpso_assessor_forward(a, stream, (int)total, r0.img01, nullptr, swarms[0].fitness, r0.class_index, r0.mode,
+                                        r0.threshold, r0.eps, nullptr, r0.w_ass, r0.w_rec, r0.workspace, r0.workspace_bytes);
+        if (rc) return rc;
+        for (int k0 = 0; k0 < n_swarms; k0 += MULTI_MAX) {
+            const int cnt = std::min(MULTI_MAX, n_swarms - k0);
+            SwarmBatch b;
+            std::memset((void *)&b, 0, sizeof(b));
+            bool small = true, dist = false;
+            int max_blocks = 1;
+            size_t lds = 0;
+            for (int j = 0; j < cnt; ++j) {
+                const gdpso_swarm &s = swarms[k0 + j];
+                const gdpso_run &r = runs[k0 + j];
+                b.s[j] = s;
+                b.rnd[j] = (r.rand && i <= s.max_iter) ? r.rand + (size_t)(i - 1) * s.n * 2 : nullptr;
+                b.seed[j] = r.seed;
+                b.w_cogn[j] = r.w_cogn;
+                b.w_soci[j] = r.w_soci;
+                b.tolerance[j] = r.tolerance;
+                b.schedule_inertia[j] = r.schedule_inertia;
+                b.early_stopping[j] = r.early_stopping;
+                b.f32_terms[j] = 0;
+                small &= s.n <= SMALL_MAX_N && (long)s.n * s.d <= SMALL_MAX_ELEMS;
+                if (r.diagnostics && s.mean_dist && s.n >= 2) {
+                    const int DT = dist_tile_side(s.d, s.n);
+                    GDPSO_REQUIRE((size_t)2 * DT * s.d * sizeof(double) <= 64 * 1024, "swarm_iterate_multi: dim_space too large");
+                    b.dist_tile[j] = DT;
+                    b.dist_tiles[j] = ceil_div(s.n, DT);
+                    b.dist_partial[j] = (double *)((char *)s.scratch + ((size_t)ceil_div(s.n, PB) * sizeof(BestRec) + 255) / 256 * 256);
+                    max_blocks = std::max(max_blocks, (int)dist_tiles(s.n, DT));
+                    lds = std::max(lds, (size_t)2 * DT * s.d * sizeof(double));
+                    dist = true;
+                } else {
+                    b.s[j].mean_dist = nullptr;  // the distance kernels skip this swarm
+                }
+            }
+            if (small) {
+                hipLaunchKernelGGL(swarm_step_small_multi_kernel, dim3(cnt), dim3(SMALL_THREADS), 0, (hipStream_t)stream, b, i);
+            } else {  // large swarms: the multi-workgroup kernels, swarm by swarm
+                for (int j = 0; j < cnt; ++j) {
+                    const gdpso_swarm &s = swarms[k0 + j];
+                    const gdpso_run &r = runs[k0 + j];
+                    if (i > s.max_iter) continue;
+                    if ((rc = gdpso_swarm_local_best(&s, stream, i, 0))) return rc;
+                    if ((rc = gdpso_swarm_global_best(&s, stream, i, r.schedule_inertia, r.early_stopping, r.tolerance))) return rc;
+                    if ((rc = gdpso_swarm_move(&s, stream, i, r.w_cogn, r.w_soci, b.rnd[j], r.seed, 0))) return rc;
+                }
+            }
+            if (dist) {
+                hipLaunchKernelGGL(pair_dist_multi_kernel, dim3(max_blocks, cnt), dim3(256), lds, (hipStream_t)stream, b, i);
+                hipLaunchKernelGGL(pair_dist_finish_multi_kernel, dim3(cnt), dim3(256), 0, (hipStream_t)stream, b, i);
+            }
+            GDPSO_HIP(hipGetLastError());
+        }
     }
     return GDPSO_OK;
 }

@@ -340,7 +340,9 @@ class HipSwarm:
     and the per-phase kernel launches.  One instance per process / GPU."""
 
     def __init__(self, evaluator: Evaluator, n_local, d, max_iter, *, first_index=0, n_ranks=1, rank=0, n_global=None,
-                 history=True, diagnostics=True, record_fitness=False):
+                 history=True, diagnostics=True, record_fitness=False, pos=None, fitness=None):
+        """``pos`` [n, d] float64 / ``fitness`` [n] float32: views into buffers owned by someone else (a
+        HipSwarmBatch lays its swarms' positions and fitness values out back to back)."""
         self.ev, self.device = evaluator, evaluator.device
         self.n, self.d, self.max_iter = int(n_local), int(d), int(max_iter)
         self.first_index, self.n_ranks, self.rank = int(first_index), int(n_ranks), int(rank)
@@ -349,11 +351,12 @@ class HipSwarm:
             raise ValueError(f"dim_space {d} != generator z_dim {evaluator.gen.z_dim}")
         dev, f64, f32 = self.device, torch.float64, torch.float32
         n, t = self.n, self.max_iter
-        self.pos = torch.zeros(n, d, dtype=f64, device=dev)
+        self.pos = torch.zeros(n, d, dtype=f64, device=dev) if pos is None else pos
         self.vel = torch.zeros(n, d, dtype=f64, device=dev)
         self.pbest_pos = torch.zeros(n, d, dtype=f64, device=dev)
         self.pbest_val = torch.zeros(n, dtype=f32, device=dev)
-        self.fitness = torch.zeros(n, dtype=f32, device=dev)
+        self.fitness = torch.zeros(n, dtype=f32, device=dev) if fitness is None else fitness
+        assert self.pos.shape == (n, d) and self.pos.is_contiguous() and self.fitness.shape == (n,)
         self.gbest_pos = torch.zeros(d, dtype=f64, device=dev)
         self.ctrl = torch.zeros(_lib.CTRL_DOUBLES, dtype=f64, device=dev)
         self.g_best_val = torch.zeros(t + 1, dtype=f32, device=dev)
@@ -466,6 +469,73 @@ class HipSwarm:
         if self.fit_hist is not None:
             out["fitness"] = self.fit_hist[:iters].cpu().numpy()
         return out
+
+
+class HipSwarmBatch:
+    """Several independent swarms that share one evaluation batch (gdpso_swarm_iterate_multi): the
+    reference runs one swarm per iid class, one after the other (src/training/pso_discovery.py:174-218);
+    here an iteration of all of them is ONE generator + assessor pass over the concatenated
+    particles.  Every swarm is a HipSwarm with its own state; positions and fitness values are
+    slices of two shared buffers."""
+
+    def __init__(self, evaluator: Evaluator, sizes, d, max_iters, *, history=True, diagnostics=True, record_fitness=False):
+        self.ev, self.device, self.d = evaluator, evaluator.device, int(d)
+        self.sizes = [int(n) for n in sizes]
+        self.total = sum(self.sizes)
+        self.pos_all = torch.zeros(self.total, d, dtype=torch.float64, device=self.device)
+        self.fit_all = torch.zeros(self.total, dtype=torch.float32, device=self.device)
+        self.swarms, off = [], 0
+        for n, t in zip(self.sizes, max_iters):
+            self.swarms.append(HipSwarm(evaluator, n, d, t, history=history, diagnostics=diagnostics, record_fitness=record_fitness,
+                                        pos=self.pos_all[off:off + n], fitness=self.fit_all[off:off + n]))
+            off += n
+        self.max_iter = max(int(t) for t in max_iters)
+        self.class_per_image = None
+
+    def iterate(self, first, count, specs, params):
+        """Iterations first .. first+count-1 of every swarm.  specs: one FitnessSpec per swarm (mode,
+        threshold and eps must agree; class_index may differ); params: per swarm a dict with w_cogn,
+        w_soci, schedule_inertia, early_stopping, tolerance, diagnostics, seed."""
+        img, img01, mse = self.ev.image_buffers(self.total)
+        ws = self.ev.workspace(self.total)
+        if self.class_per_image is None:
+            cls = np.concatenate([np.full(n, sp.class_index, np.int32) for n, sp in zip(self.sizes, specs)])
+            self.class_per_image = torch.from_numpy(cls).to(self.device)
+        k = len(self.swarms)
+        descs = (_lib.SwarmDesc * k)(*[s.desc for s in self.swarms])
+        runs = (_lib.RunDesc * k)()
+        for j, (s, sp, pr) in enumerate(zip(self.swarms, specs, params)):
+            runs[j] = _lib.RunDesc(class_index=sp.class_index, mode=sp.mode_code(), threshold=sp.threshold, eps=sp.eps, target=0,
+                                   w_ass=sp.w_ass, w_rec=sp.w_rec, w_cogn=pr["w_cogn"], w_soci=pr["w_soci"],
+                                   schedule_inertia=int(pr["schedule_inertia"]), early_stopping=int(pr["early_stopping"]),
+                                   tolerance=pr["tolerance"], rand=ptr(s.rand), seed=int(pr.get("seed", 0)),
+                                   diagnostics=int(bool(pr.get("diagnostics", True)) and s.mean_dist is not None), f32_first_move=0,
+                                   img01=ptr(img01), img=ptr(img), mse=ptr(mse), workspace=ptr(ws), workspace_bytes=ws.numel())
+        record = any(s.fit_hist is not None for s in self.swarms)
+        with torch.cuda.device(self.device):
+            stream = _lib.stream_handle(self.device)
+            step = 1 if record else count
+            for i in range(first, first + count, step):
+                check(_lib.lib().gdpso_swarm_iterate_multi(descs, runs, k, self.ev.gen.h, self.ev.ass.h, ptr(self.class_per_image),
+                                                           stream, i, step))
+                if record:
+                    for s in self.swarms:
+                        if s.fit_hist is not None and i <= s.max_iter:
+                            s.fit_hist[i - 1].copy_(s.fitness)
+
+    def run(self, specs, params, poll_every=8):
+        """All iterations; with early stopping the host looks at the stop flags every few iterations
+        and ends the loop once every swarm has stopped."""
+        i = 1
+        any_es = any(p["early_stopping"] for p in params)
+        while i <= self.max_iter:
+            chunk = min(poll_every, self.max_iter - i + 1) if any_es else self.max_iter - i + 1
+            self.iterate(i, chunk, specs, params)
+            i += chunk
+            if any_es and i <= self.max_iter:
+                done = [int(s.control()[_lib.CTRL_STOP_ITER]) != 0 or i > s.max_iter for s in self.swarms]
+                if all(done):
+                    break
 
 
 # -------------------------------------------------------------------------- the loops

@@ -57,6 +57,15 @@ class Discovery:
             self._evaluator_key = key
         return self._evaluator
 
+    def share_evaluator_with(self, other: "Discovery"):
+        """Adopts ``other``'s packed device copy when both wrap the very same model objects, device and
+        precision (several Discovery objects that differ only in iid_class then pack the weights once)."""
+        if (other.model_gan is self.model_gan and other.model_cnn is self.model_cnn and other.device == self.device
+                and other.compute_dtype == self.compute_dtype):
+            self._evaluator, self._evaluator_key = other.evaluator(), other._evaluator_key
+            return True
+        return False
+
     def fitness_spec(self, eps=0.1, w_ass=1.0, w_rec=1.0) -> engine.FitnessSpec:
         n_class = self.evaluator().ass.n_class
         # more than two classes: the posterior of this swarm's class; otherwise index 1

@@ -139,8 +139,13 @@ class Swarm:
             # leave numpy's stream where the reference would have left it
             np.random.set_state(rng_state)
             np.random.random((iters, n, 2))
+        return self._finish(res, n, targets, sw.pos if comm is None else None)
+
+    def _finish(self, res, n, targets, device_pos):
+        """Publishes a finished run on this object and builds optimize()'s return value."""
+        t, iters = self.n_iterations, res["iters"]
         self.results = res
-        self._device_pos = sw.pos if comm is None else None
+        self._device_pos = device_pos
         self._publish(res, n, targets)
 
         history = {"mean_mse": [float(x) for x in res.get("mean_mse", [])], "global_best_val": []}
@@ -207,3 +212,46 @@ class Swarm:
         path = os.path.join(self.plot_training_dir, f"pso_images_{iteration if iteration is not None else 'final'}.npy")
         np.save(path, img01.cpu().numpy())
         return path
+
+
+def optimize_swarms(swarms, schedule_inertia=False, early_stopping=True):
+    """``[sw.optimize(schedule_inertia, early_stopping) for sw in swarms]`` with every iteration of
+    all the swarms evaluated as ONE batch through the generator and the assessor.
+
+    Not in the reference, which builds one Swarm per iid class and runs them one after the other
+    (src/training/pso_discovery.py:174-218: 8 classes x 32 particles); swarms of 32 particles leave the
+    GPU idle between ~70 short launches per iteration, 8 of them in one 256-image batch cost about
+    one iteration of one.  The swarms must share the generator, the assessor, device, fitness mode,
+    threshold and dim_space (their ``discovery.iid_class`` is what differs).  Every swarm comes out
+    as if it had run alone on the same draws.  numpy's global stream is consumed swarm by swarm in
+    the reference's order (positions and velocities, then r1, r2 for every iteration); with early
+    stopping a swarm that stops at iteration i still consumes the draws of all its n_iterations
+    (the sequential reference would hand the unused ones to the next swarm), so to reproduce a
+    sequential early-stopped reference run exactly, run the swarms sequentially."""
+    if not swarms:
+        return []
+    first = swarms[0]
+    ev = first.discovery.evaluator()
+    specs, draws = [], []
+    for sw in swarms:
+        if sw.dim_space != first.dim_space or sw.device != first.device:
+            raise ValueError("optimize_swarms: the swarms must share dim_space and device")
+        if sw is not first and not sw.discovery.share_evaluator_with(first.discovery):
+            raise ValueError("optimize_swarms: the swarms must share one generator, one assessor, device and precision")
+        specs.append(sw.discovery.fitness_spec())
+        n, d, t = sw.num_particles, sw.dim_space, sw.n_iterations
+        r = np.random.randn(n, 2, d)
+        rand = np.random.random((t, n, 2)) if sw.device_rng_seed is None else None
+        draws.append((r[:, 0, :].copy(), (r[:, 1, :] - 0.5) / 10, rand))
+    if len({(sp.mode, sp.threshold, sp.eps) for sp in specs}) != 1:
+        raise ValueError("optimize_swarms: the swarms must share control_pso_fitness, threshold and eps")
+    batch = engine.HipSwarmBatch(ev, [sw.num_particles for sw in swarms], first.dim_space, [sw.n_iterations for sw in swarms],
+                                 history=all(sw.record_history for sw in swarms), diagnostics=all(sw.diagnostics for sw in swarms),
+                                 record_fitness=any(sw.record_fitness for sw in swarms))
+    params = []
+    for sw, hs, (pos0, vel0, rand) in zip(swarms, batch.swarms, draws):
+        hs.load(pos0, vel0, sw.w_inertia, rand=rand)
+        params.append(dict(w_cogn=sw.w_cogn, w_soci=sw.w_soci, schedule_inertia=schedule_inertia, early_stopping=early_stopping,
+                           tolerance=sw.tolerance, diagnostics=sw.diagnostics, seed=sw.device_rng_seed or 0))
+    batch.run(specs, params)
+    return [sw._finish(hs.results(), sw.num_particles, None, hs.pos) for sw, hs in zip(swarms, batch.swarms)]

@@ -243,6 +243,29 @@ typedef struct {
 int gdpso_swarm_iterate(const gdpso_swarm *s, const gdpso_generator *g, const gdpso_assessor *a,
                         const gdpso_run *r, void *stream, int first_iteration, int n_iterations);
 
+/* img01 -> fitness as gdpso_assessor_forward, with the class of interest given per image
+ * (class_per_image: DEVICE int [n]): several swarms, each after its own class, in one batch. */
+int gdpso_assessor_forward_classes(const gdpso_assessor *a, void *stream, int n, const float *img01, float *logits,
+                                   float *fitness, const int *class_per_image, int mode, float threshold, float eps,
+                                   const float *mse, float w_ass, float w_rec, void *workspace, size_t workspace_bytes);
+
+/* Several independent swarms through ONE generator + assessor batch per iteration: the reference
+ * walks its iid classes one after the other with a swarm each (src/training/pso_discovery.py:174-218,
+ * 8 classes x 32 particles in configs/dcgan_mnist.yaml:17-24,146-156); batched, an iteration of all
+ * of them costs one network pass over the concatenated particles.  Every swarm keeps its own global
+ * best, inertia, draws, stopping state and max_iter (a swarm past its max_iter or stopped early is
+ * skipped) and comes out exactly as gdpso_swarm_iterate would leave it given the same fitness values.
+ * swarms / runs: HOST arrays of n_swarms descriptors.  Requirements: one dim_space; n_ranks == 1; the
+ * swarms' pos and fitness buffers are consecutive slices of one buffer, in order (that buffer is the
+ * evaluation batch); runs[k] gives swarm k its w_cogn / w_soci / schedule / stopping / rand / seed /
+ * diagnostics; mode, threshold, eps are shared; runs[0] carries the shared img / img01 / workspace
+ * (sized for all particles together).  class_per_image: DEVICE int [all particles], or NULL when the
+ * assessor has two classes or there is one swarm (then runs[0].class_index).  Not for the
+ * inverter variant (target must be NULL). */
+int gdpso_swarm_iterate_multi(const gdpso_swarm *swarms, const gdpso_run *runs, int n_swarms, const gdpso_generator *g,
+                              const gdpso_assessor *a, const int *class_per_image, void *stream, int first_iteration,
+                              int n_iterations);
+
 /* ------------------------------------------------------- vector quantisation (VQ-VAE)
  * The step after the PSO run in the reference's VQ-VAE workflow.  All buffers on the device,
  * row-major fp32 unless noted; `codebook` is [k, d] (nn.Embedding(K, D).weight).

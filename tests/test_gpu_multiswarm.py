@@ -1,0 +1,132 @@
+"""Several independent swarms evaluated as one batch (gdpso_swarm_iterate_multi, engine.HipSwarmBatch,
+util_pso.optimize_swarms): the reference walks its iid classes one after the other with a swarm each
+(src/training/pso_discovery.py:174-218); batched, every swarm must come out as if it had run alone."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from parity_utils import first_ambiguous_iteration
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+FIXTURES = ["swarm_n8_t5_z10", "swarm_n12_t40_z10_es", "swarm_n64_t50_z10"]  # same networks, different n / T / class / stopping
+
+
+@pytest.fixture(scope="module")
+def eng():
+    return importlib.import_module("gan-discovery-pso_amd.engine")
+
+
+@pytest.fixture(scope="module")
+def ev(eng, synth):
+    dev = torch.device("cuda:0")
+    return eng.Evaluator(eng.PackedGenerator(synth.generator_state(10, 1, 64, seed=11), dev),
+                         eng.PackedAssessor(synth.resnet_state("ResNet50", 1, 8, seed=12), dev, img_side=28))
+
+
+def _load_batch(eng, ev, goldens, replace=None):
+    batch = eng.HipSwarmBatch(ev, [int(g["n"]) for g in goldens], 10, [int(g["t"]) for g in goldens], record_fitness=True)
+    specs, params = [], []
+    for k, (g, hs) in enumerate(zip(goldens, batch.swarms)):
+        pos0, vel0, rand = g["pos"][0], g["vel"][0], g["rand"]
+        if replace is not None and k in replace:
+            rs = np.random.RandomState(replace[k])
+            pos0, vel0, rand = rs.standard_normal(pos0.shape), rs.standard_normal(vel0.shape) * 0.1, rs.random_sample((int(g["t"]),) + rand.shape[1:])
+        if rand.shape[0] < int(g["t"]):  # a run that stopped early recorded only the draws it used
+            rand = np.concatenate([rand, np.zeros((int(g["t"]) - rand.shape[0],) + rand.shape[1:])])
+        hs.load(pos0, vel0, float(g["w"][0]), rand=rand)
+        specs.append(eng.FitnessSpec(class_index=sorted(g["iid"].tolist()).index(int(g["label"]))))
+        params.append(dict(w_cogn=float(g["w"][1]), w_soci=float(g["w"][2]), schedule_inertia=bool(g["schedule_inertia"]),
+                           early_stopping=bool(g["early_stopping"]), tolerance=float(g["tolerance"]), diagnostics=True))
+    return batch, specs, params
+
+
+def test_batched_swarms_follow_the_reference_trajectories(eng, ev):
+    """Three recorded reference runs (8 x 5 iterations, 12 x 40 with early stopping at 19, 64 x 50; two
+    different classes) as ONE batch of 84 particles: each follows its own recorded trajectory bit for
+    bit for as long as its decisions are clear of fp32 noise, stops where the reference stopped, and
+    keeps its own bookkeeping."""
+    goldens = [load_golden(n) for n in FIXTURES]
+    batch, specs, params = _load_batch(eng, ev, goldens)
+    batch.run(specs, params)
+    for g, hs in zip(goldens, batch.swarms):
+        res = hs.results()
+        iters = g["fitness"].shape[0]
+        safe = first_ambiguous_iteration(g["fitness"], 2e-5)
+        np.testing.assert_allclose(res["fitness"][:safe], g["fitness"][:safe], atol=TOL)
+        np.testing.assert_array_equal(res["hist_pos"][:safe + 1], g["pos"][:safe + 1])
+        np.testing.assert_array_equal(res["hist_vel"][:safe + 1], g["vel"][:safe + 1])
+        np.testing.assert_allclose(res["mean_mse"][:safe], g["mean_mse"][:safe], rtol=1e-12)
+        np.testing.assert_allclose(res["g_best_val_dummy"][:safe], g["g_best_val_dummy"][:safe], atol=TOL)
+        if safe == iters:
+            assert res["iters"] == iters and res["stopped"] == (int(g["i_ret"]) <= int(g["t"]))
+            np.testing.assert_array_equal(res["g_best_pos"], g["g_best_pos"])
+            np.testing.assert_allclose(res["g_best_val"], g["g_best_val"], atol=TOL)
+            np.testing.assert_array_equal(res["pbest_pos"], g["pbest_pos"])
+    assert batch.swarms[1].results()["stopped"] and not batch.swarms[0].results()["stopped"]
+
+
+def test_a_swarm_does_not_see_its_batch_mates(eng, ev):
+    """Bit for bit: the same swarm next to two different neighbours (same batch layout, so the same
+    launch plan) produces identical fitness values, positions and bests."""
+    goldens = [load_golden(n) for n in FIXTURES]
+    runs = []
+    for replace in (None, {0: 101, 2: 102}):
+        batch, specs, params = _load_batch(eng, ev, goldens, replace)
+        batch.run(specs, params)
+        runs.append([hs.results() for hs in batch.swarms])
+    a, b = runs[0][1], runs[1][1]
+    for key in ("fitness", "hist_pos", "hist_vel", "g_best_val", "g_best_pos", "pbest_val", "mean_mse"):
+        np.testing.assert_array_equal(a[key], b[key])
+    assert not np.array_equal(runs[0][0]["hist_pos"], runs[1][0]["hist_pos"])  # the neighbours did differ
+
+
+def test_eight_classes_of_32_particles_as_one_batch(eng, synth):
+    """The reference's real workload (8 iid classes x 32 particles, configs/dcgan_mnist.yaml) through
+    the reference-style classes: optimize_swarms against the same eight Swarm.optimize calls made
+    one after the other on the same numpy stream."""
+    imp = lambda m: importlib.import_module("gan-discovery-pso_amd." + m)
+    dev = torch.device("cuda:0")
+    iid = [0, 2, 3, 4, 6, 7, 8, 9]
+    gen = imp("utils.util_dcgan").Generator(10, 1, 64).to(dev)
+    gen.load_state_dict(synth.to_torch(synth.generator_state(10, 1, 64, seed=11)))
+    cnn = imp("pso.util_cnn").get_cnn("ResNet50", 1, iid, 8).to(dev)
+    cnn.load_state_dict(synth.to_torch(synth.resnet_state("ResNet50", 1, 8, seed=12)))
+    pso = imp("pso.util_pso")
+    n, t, d = 32, 10, 10
+
+    def make():
+        out = []
+        for label in iid:
+            disc = imp("pso.util_discovery").Discovery(label, gen, cnn, dev, iid_classes=iid)
+            sw = pso.Swarm("/tmp/gdpso_test", disc, n, t, d, dev, tolerance=1e-5, w_inertia=0.73, w_cogn=1.496, w_soci=1.496)
+            sw.verbose, sw.record_fitness = False, True
+            out.append(sw)
+        return out
+
+    np.random.seed(5)
+    together = make()
+    rets = pso.optimize_swarms(together, schedule_inertia=False, early_stopping=False)
+    after_batched = np.random.random()
+    np.random.seed(5)
+    alone = make()
+    for sw in alone:
+        sw.optimize(schedule_inertia=False, early_stopping=False)
+    assert np.random.random() == after_batched  # the stream was consumed the same way
+    assert len(rets) == 8 and all(r[3] == t + 1 for r in rets)
+    compared = 0
+    for a, b, ret in zip(alone, together, rets):
+        ra, rb = a.results, b.results
+        np.testing.assert_array_equal(rb["hist_pos"][0], ra["hist_pos"][0])
+        # batch sizes 32 and 256 take different tile shapes, hence different fp32 summation orders
+        safe = first_ambiguous_iteration(ra["fitness"], 2e-5)
+        np.testing.assert_allclose(rb["fitness"][:safe], ra["fitness"][:safe], atol=2e-5)
+        np.testing.assert_array_equal(rb["hist_pos"][:safe + 1], ra["hist_pos"][:safe + 1])
+        np.testing.assert_allclose(rb["g_best_val_dummy"][:safe], ra["g_best_val_dummy"][:safe], atol=2e-5)
+        assert sorted(ret[1].keys()) == [f"particle_{k}" for k in sorted(range(n), key=str)]
+        compared += safe
+    assert compared >= 8 * 3  # the comparison is not vacuous
+    assert len({float(sw.g_best_val[-1][0]) for sw in together}) > 1  # the classes do differ
