@@ -35,33 +35,65 @@ sys.path.insert(0, ROOT)
 # MI355X dense matrix-instruction peaks by operand type: fp32-input MFMA (= the fp32 vector peak), and
 # the 16-bit forms (about 2.5 PFLOP/s dense; the headline figures twice that include 2:1 sparsity)
 PEAK_MFMA_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0}
+TRAFFIC_FILE = "r2_hbm_traffic.json"  # PMC summary of the default command (tools/refresh_profiles.sh)
+
+
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(z_dim, n_class, class_index, seconds_budget=20.0):
-    """The oracle's restatement of the reference loop (one particle per forward pass,
-    pairwise-distance diagnostic on, no plotting), timed on this box's host cores on a
-    bounded sample: 64 particles, as many iterations as fit the budget (at least 1)."""
+    """The oracle's restatement of the reference loop, timed on this box's host cores on bounded
+    samples of the benchmark's workload (64 particles, as many iterations as fit each mode's share
+    of the budget, at least 1; pairwise-distance diagnostic on, no plotting):
+
+    * faithful: one particle per forward pass, the way the reference's loop calls its networks
+      (src/pso/util_pso.py:117-125) -- `value` is this mode on all the threads used;
+    * batched: one torch-CPU batch per iteration (the same arithmetic, not how the reference runs);
+    each on `cores` threads (this job's CPU share: 16 per GPU on the GPU box, or every CPU of a
+    smaller host) and on 1 thread."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pso_oracle as oracle
     synth = importlib.import_module("gan-discovery-pso_amd.synth")
-    threads = min(16, os.cpu_count() or 1)
-    torch.set_num_threads(threads)
+    host_cpus = os.cpu_count() or 1
+    threads = min(16, host_cpus)
     gsd = synth.to_torch(synth.generator_state(z_dim, 1, 64, seed=11))
     csd = synth.to_torch(synth.resnet_state("ResNet50", 1, n_class, seed=12))
     fit = oracle.Fitness(gsd, csd, class_index)
-    rs = np.random.RandomState(42)
     n = 64
-    pos, vel = oracle.init_swarm(n, z_dim, rs)
-    fit(pos[:2])  # first-touch of the torch CPU kernels is not what is being measured
-    t0 = time.perf_counter()
-    oracle.run_swarm(fit, pos, vel, 1, 0.73, 1.496, 1.496, early_stopping=False, rng=rs, batch=1, record=False)
-    one = time.perf_counter() - t0
-    iters = int(max(1, min(8, seconds_budget // max(one, 1e-3))))
-    t0 = time.perf_counter()
-    oracle.run_swarm(fit, pos, vel, iters, 0.73, 1.496, 1.496, early_stopping=False, rng=rs, batch=1, record=False)
-    dt = time.perf_counter() - t0
-    return {"value": round(n * iters / dt, 2), "unit": "particle-evals/s", "cores": threads, "kind": "port",
-            "sample": f"{n} particles x {iters} iterations, one particle per forward pass (reference-style loop), torch CPU fp32"}
+
+    def timed(batch, nthreads, budget, max_iters):
+        torch.set_num_threads(nthreads)
+        rs = np.random.RandomState(42)
+        pos, vel = oracle.init_swarm(n, z_dim, rs)
+        fit(pos[:2])  # first-touch of the torch CPU kernels is not what is being measured
+        t0 = time.perf_counter()
+        oracle.run_swarm(fit, pos, vel, 1, 0.73, 1.496, 1.496, early_stopping=False, rng=rs, batch=batch, record=False)
+        one = time.perf_counter() - t0
+        iters = int(max(1, min(max_iters, (budget - one) // max(one, 1e-3))))
+        t0 = time.perf_counter()
+        oracle.run_swarm(fit, pos, vel, iters, 0.73, 1.496, 1.496, early_stopping=False, rng=rs, batch=batch, record=False)
+        dt = time.perf_counter() - t0
+        return round(n * iters / dt, 2), iters
+
+    share = seconds_budget / 4
+    f_all, it_fa = timed(1, threads, 2 * share, 8)
+    b_all, it_ba = timed(n, threads, share / 2, 8)
+    f_one, it_f1 = timed(1, 1, share, 2)
+    b_one, it_b1 = timed(n, 1, share / 2, 2)
+    torch.set_num_threads(threads)
+    return {"value": f_all, "unit": "particle-evals/s", "cores": threads, "kind": "port",
+            "sample": f"{n} particles x {it_fa} iterations, one particle per forward pass (reference-style loop), torch CPU fp32",
+            "host_cpus": host_cpus, "cpu_model": _cpu_model(),
+            "modes": {"faithful": {f"{threads}_threads": f_all, "1_thread": f_one, "iterations": [it_fa, it_f1]},
+                      "batched": {f"{threads}_threads": b_all, "1_thread": b_one, "iterations": [it_ba, it_b1]}}}
 
 
 def launch_ranks(n_ranks, argv):
@@ -263,7 +295,7 @@ def main():
         # read from inside the process); null when the summary is absent or was taken at another size
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as f:
                 pm = json.load(f)
             if p == 512 and z_dim == 10 and args.side == 28 and args.dtype == "f32":
                 traffic = pm["kernels"]["conv_gemm (all instantiations)"]["hbm_bytes_per_launch"]
@@ -273,7 +305,7 @@ def main():
         roofline = {"bound": "mfma", "kernel": f"conv_gemm_kernel / conv_gemm_pair_kernel / conv_gemm_fused_kernel, all instantiations ({args.dtype}-input MFMA implicit GEMM)",
                     "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic,
-                    "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_hbm_traffic.json)",
+                    "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/" + TRAFFIC_FILE + ")",
                     "algorithmic_bytes_per_launch": round(alg_bytes),
                     "launches_per_step": launches.value // k, "avg_launch_us": round(1e3 * ms.value / launches.value, 3),
                     "conv_ms_per_step": round(ms.value / k, 4),

@@ -1186,11 +1186,20 @@ extern "C" int gdpso_conv_plan_describe(int n_images, int hin, int cin, int cout
 // the planner's choice.
 extern "C" int gdpso_conv_probe(int n_images, int hin, int cin, int cout, int ksize, int stride, int pad, int tile,
                                 int splits, int with_res, int reps, double *avg_us, int *tile_used, int *splits_used) {
+    return gdpso_conv_probe_typed(n_images, hin, cin, cout, ksize, stride, pad, tile, splits, with_res, reps, avg_us, tile_used,
+                                  splits_used, GDPSO_DTYPE_F32);
+}
+
+extern "C" int gdpso_conv_probe_typed(int n_images, int hin, int cin, int cout, int ksize, int stride, int pad, int tile,
+                                      int splits, int with_res, int reps, double *avg_us, int *tile_used, int *splits_used,
+                                      int dtype) {
     using namespace gdpso;
-    GDPSO_REQUIRE(n_images > 0 && hin > 0 && cin % 32 == 0 && cout % 64 == 0 && reps > 0 && avg_us, "conv_probe: bad argument");
+    GDPSO_REQUIRE(dtype_ok(dtype), "conv_probe: unknown dtype");
+    const int kq = dtype_kquant(dtype);
+    GDPSO_REQUIRE(n_images > 0 && hin > 0 && cin % kq == 0 && cout % 64 == 0 && reps > 0 && avg_us, "conv_probe: bad argument");
     GDPSO_REQUIRE(ksize > 0 && stride > 0 && pad >= 0 && hin + 2 * pad >= ksize && conv_window_fits(ksize, pad),
                   "conv_probe: bad window (at most 64 taps, offsets within +-127)");
-    GDPSO_REQUIRE(tile == 0 || tile == 64 || (tile == 32 && cin % 64 == 0) || (tile == TILE_32x32 && cin % 128 == 0) ||
+    GDPSO_REQUIRE(tile == 0 || tile == 64 || (tile == 32 && cin % (2 * kq) == 0) || (tile == TILE_32x32 && cin % (4 * kq) == 0) ||
                       (tile == 128 && cout % 128 == 0),
                   "conv_probe: bad tile");
     std::vector<float> w((size_t)cout * cin * ksize * ksize), packed, sc(cout, 1.f), sh(cout, 0.1f);
@@ -1200,7 +1209,7 @@ extern "C" int gdpso_conv_probe(int n_images, int hin, int cin, int cout, int ks
     ConvLayer L;
     make_conv(L, w.data(), cout, cin, ksize, ksize, stride, pad, hin, hin, ACT_RELU, packed);
     DeviceArena arena;
-    int rc = upload_conv(arena, L, packed, sc, sh);
+    int rc = upload_conv(arena, L, packed, sc, sh, dtype);
     if (rc) return rc;
     int dev = 0, cus = 256;
     GDPSO_HIP(hipGetDevice(&dev));
@@ -1209,11 +1218,18 @@ extern "C" int gdpso_conv_probe(int n_images, int hin, int cin, int cout, int ks
     if (tile) L.tile = tile;
     if (splits) L.splits = splits;
     const size_t in_elems = (size_t)n_images * hin * hin * cin, out_elems = (size_t)n_images * L.hout * L.wout * cout;
-    std::vector<float> hin_v(in_elems);
-    for (auto &v : hin_v) v = rnd();
-    const float *d_in = nullptr;
-    if ((rc = arena.upload(hin_v, &d_in))) return rc;
-    float *d_out = nullptr, *d_res = nullptr, *d_sk = nullptr;
+    const void *d_in = nullptr;
+    if (dtype == DT_F32) {
+        std::vector<float> hin_v(in_elems);
+        for (auto &v : hin_v) v = rnd();
+        if ((rc = arena.upload(hin_v.data(), in_elems * 4, &d_in))) return rc;
+    } else {
+        std::vector<uint16_t> hin_v(in_elems);
+        for (auto &v : hin_v) v = dtype == DT_BF16 ? f32_to_bf16_bits(rnd()) : f32_to_f16_bits(rnd());
+        if ((rc = arena.upload(hin_v.data(), in_elems * 2, &d_in))) return rc;
+    }
+    void *d_out = nullptr, *d_res = nullptr;
+    float *d_sk = nullptr;
     GDPSO_HIP(hipMalloc(&d_out, out_elems * 4));
     arena.blocks.push_back(d_out);
     GDPSO_HIP(hipMalloc(&d_res, out_elems * 4));

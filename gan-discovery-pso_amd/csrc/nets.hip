@@ -4,6 +4,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
 
 #include "common.h"
 
@@ -566,7 +569,12 @@ static size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 using namespace gdpso;
 
 // ============================================================================ generator
+struct GenLayout;
 struct gdpso_generator {
+    // launch plans by batch size, made on first use (planning every layer again on every forward
+    // pass was a measurable part of the host's enqueue time)
+    mutable std::mutex plan_mutex;
+    mutable std::map<int, std::shared_ptr<const GenLayout>> plans;
     int dtype;  // DType of the activations between the layers and of the convolution weights
     int z_dim, kpad, features, k1, side;
     ConvLayer l1, l2;
@@ -578,16 +586,23 @@ struct gdpso_generator {
     DeviceArena arena;
 };
 
-namespace {
 struct GenLayout {
     size_t zpad, a1, a2, splitk, total;
+    ConvLayer l1, l2;  // the handle's layers with the launch plan for this batch size
 };
-GenLayout gen_layout(const gdpso_generator *g, int n, ConvLayer &l1, ConvLayer &l2) {
+namespace {
+constexpr size_t MAX_CACHED_PLANS = 16;
+std::shared_ptr<const GenLayout> gen_layout(const gdpso_generator *g, int n) {
+    std::lock_guard<std::mutex> lock(g->plan_mutex);
+    auto it = g->plans.find(n);
+    if (it != g->plans.end()) return it->second;
+    auto Lp = std::make_shared<GenLayout>();
+    GenLayout &L = *Lp;
+    ConvLayer &l1 = L.l1, &l2 = L.l2;
     l1 = g->l1;
     l2 = g->l2;
     plan_conv(l1, n, g->num_cus);
     plan_conv(l2, n, g->num_cus);
-    GenLayout L;
     size_t off = 0;
     const size_t es = dtype_size(g->dtype);
     L.zpad = off; off += align_up((size_t)n * g->kpad * es);
@@ -595,7 +610,9 @@ GenLayout gen_layout(const gdpso_generator *g, int n, ConvLayer &l1, ConvLayer &
     L.a2 = off;   off += align_up((size_t)n * 4 * g->k1 * g->k1 * g->features * es);
     L.splitk = off; off += align_up(std::max(conv_splitk_bytes(l1, n), conv_splitk_bytes(l2, n)));
     L.total = off;
-    return L;
+    if (g->plans.size() >= MAX_CACHED_PLANS) g->plans.clear();
+    g->plans[n] = Lp;
+    return Lp;
 }
 }  // namespace
 
@@ -676,8 +693,7 @@ extern "C" int gdpso_generator_image_side(const gdpso_generator *g) { return g ?
 
 extern "C" size_t gdpso_generator_workspace_bytes(const gdpso_generator *g, int n) {
     if (!g || n <= 0) return 0;
-    ConvLayer a, b;
-    return gen_layout(g, n, a, b).total;
+    return gen_layout(g, n)->total;
 }
 
 extern "C" int gdpso_generator_forward(const gdpso_generator *g, void *stream_, int n, const void *z, int z_is_f64,
@@ -687,8 +703,9 @@ extern "C" int gdpso_generator_forward(const gdpso_generator *g, void *stream_, 
     GDPSO_REQUIRE(n > 0, "generator_forward: n must be positive");
     GDPSO_REQUIRE((target == nullptr) == (mse == nullptr), "generator_forward: target and mse go together");
     hipStream_t stream = (hipStream_t)stream_;
-    ConvLayer l1, l2;
-    const GenLayout L = gen_layout(g, n, l1, l2);
+    const std::shared_ptr<const GenLayout> plan = gen_layout(g, n);
+    const GenLayout &L = *plan;
+    const ConvLayer &l1 = L.l1, &l2 = L.l2;
     if (workspace_bytes < L.total) return fail(GDPSO_ERR_WORKSPACE, "generator_forward: workspace too small");
     char *ws = (char *)workspace;
     void *zpad = ws + L.zpad, *a1 = ws + L.a1, *a2 = ws + L.a2;
@@ -725,7 +742,10 @@ struct Bottleneck {
     bool has_ds;
 };
 
+struct AssLayout;
 struct gdpso_assessor {
+    mutable std::mutex plan_mutex;  // launch plans by batch size, made on first use
+    mutable std::map<int, std::shared_ptr<const AssLayout>> plans;
     int dtype;  // DType of the feature maps and of the convolution weights
     int n_class, side, ho, hp, stem_band, stem_ps;
     const float *stem_w, *stem_scale, *stem_shift;
@@ -737,13 +757,17 @@ struct gdpso_assessor {
     DeviceArena arena;
 };
 
-namespace {
 struct AssLayout {
     size_t x, y, t1, t2, sc, splitk, total;
     std::vector<Bottleneck> blocks;
 };
-AssLayout ass_layout(const gdpso_assessor *a, int n) {
-    AssLayout L;
+namespace {
+std::shared_ptr<const AssLayout> ass_layout(const gdpso_assessor *a, int n) {
+    std::lock_guard<std::mutex> lock(a->plan_mutex);
+    auto it = a->plans.find(n);
+    if (it != a->plans.end()) return it->second;
+    auto Lp = std::make_shared<AssLayout>();
+    AssLayout &L = *Lp;
     L.blocks = a->blocks;
     size_t xy = (size_t)n * a->hp * a->hp * 64, t1 = 0, t2 = 0, sc = 0, sk = 0;
     auto out_elems = [&](const ConvLayer &c) { return (size_t)n * c.hout * c.wout * c.cout; };
@@ -770,7 +794,9 @@ AssLayout ass_layout(const gdpso_assessor *a, int n) {
     L.sc = off; off += align_up(sc * es);
     L.splitk = off; off += align_up(sk);
     L.total = off;
-    return L;
+    if (a->plans.size() >= MAX_CACHED_PLANS) a->plans.clear();
+    a->plans[n] = Lp;
+    return Lp;
 }
 }  // namespace
 
@@ -866,7 +892,7 @@ extern "C" int gdpso_assessor_n_class(const gdpso_assessor *a) { return a ? a->n
 extern "C" double gdpso_assessor_flops_per_image(const gdpso_assessor *a) { return a ? a->flops : 0.0; }
 extern "C" size_t gdpso_assessor_workspace_bytes(const gdpso_assessor *a, int n) {
     if (!a || n <= 0) return 0;
-    return ass_layout(a, n).total;
+    return ass_layout(a, n)->total;
 }
 
 static int assessor_forward_impl(const gdpso_assessor *a, void *stream_, int n, const float *img01, float *logits,
@@ -880,7 +906,8 @@ static int assessor_forward_impl(const gdpso_assessor *a, void *stream_, int n, 
     GDPSO_REQUIRE(!fitness || a->n_class == 2 || class_per_image || (class_index >= 0 && class_index < a->n_class),
                   "assessor_forward: class_index out of range");
     hipStream_t stream = (hipStream_t)stream_;
-    const AssLayout L = ass_layout(a, n);
+    const std::shared_ptr<const AssLayout> plan = ass_layout(a, n);
+    const AssLayout &L = *plan;
     if (workspace_bytes < L.total) return fail(GDPSO_ERR_WORKSPACE, "assessor_forward: workspace too small");
     char *ws = (char *)workspace;
     void *x = ws + L.x, *y = ws + L.y, *t1 = ws + L.t1, *t2 = ws + L.t2, *sc = ws + L.sc;

@@ -344,6 +344,10 @@ unsigned gdpso_fast_div_check(unsigned n, unsigned d);
 int gdpso_conv_probe(int n_images, int hin, int cin, int cout, int ksize, int stride, int pad, int tile,
                      int splits, int with_res, int reps, double *avg_us, int *tile_used, int *splits_used);
 
+/* The same for a layer stored as `dtype` (GDPSO_DTYPE_*). */
+int gdpso_conv_probe_typed(int n_images, int hin, int cin, int cout, int ksize, int stride, int pad, int tile,
+                           int splits, int with_res, int reps, double *avg_us, int *tile_used, int *splits_used, int dtype);
+
 /* No counterpart in the reference: runs ONE convolution layer on the caller's data (a test
  * aid; whole-network calls reach a tile shape or split count only by way of the planner).
  * weight / scale / shift are HOST arrays: weight in PyTorch layout, [cout][cin][k][k], or

@@ -26,9 +26,13 @@ RESNET50_28 = [
 ]
 
 
+DTYPE = 0
+
+
 def probe(n, hin, cin, cout, k, stride, pad, tile, splits, res, reps=20):
     us, tu, su = C.c_double(), C.c_int(), C.c_int()
-    lib.check(lib.lib().gdpso_conv_probe(n, hin, cin, cout, k, stride, pad, tile, splits, res, reps, C.byref(us), C.byref(tu), C.byref(su)))
+    lib.check(lib.lib().gdpso_conv_probe_typed(n, hin, cin, cout, k, stride, pad, tile, splits, res, reps, C.byref(us), C.byref(tu),
+                                               C.byref(su), DTYPE))
     return us.value, tu.value, su.value
 
 
@@ -36,7 +40,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=512)
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--dtype", choices=sorted(lib.DTYPES), default="f32")
     args = ap.parse_args()
+    global DTYPE
+    DTYPE = lib.DTYPES[args.dtype]
+    kq = 32 if args.dtype == "f32" else 64
     total_plan = total_best = 0.0
     for name, hin, cin, cout, k, stride, pad, res, count in RESNET50_28:
         hout = (hin + 2 * pad - k) // stride + 1
@@ -45,10 +53,10 @@ def main():
         line = f"{name:7s} M={args.n * hout * hout:6d} K={cin * k * k:5d} N={cout:5d}  plan t{t0} s{s0}: {us0:6.1f}us {flops / us0 / 1e6:6.1f}TF |"
         best = (us0, t0, s0)
         if not args.quick:
-            for tile in (16, 32, 64):
-                if (tile == 16 and cin % 128) or (tile == 32 and cin % 64):
+            for tile in (16, 32, 64, 128):
+                if (tile == 16 and cin % (4 * kq)) or (tile == 32 and cin % (2 * kq)) or (tile == 128 and cout % 128):
                     continue
-                for splits in (1, 2, 4):
+                for splits in (1, 2) if tile == 128 else (1, 2, 4):
                     if splits > 1 and cin * k * k // splits < 64:
                         continue
                     us, _, _ = probe(args.n, hin, cin, cout, k, stride, pad, tile, splits, res)

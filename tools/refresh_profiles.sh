@@ -5,19 +5,23 @@
 # one counter each, with the program directly after "--".
 set -e
 TAG=${1:-r1}
-OUT=gpurun_out/refresh
+shift || true
+ARGS="$@"                     # extra bench.py arguments, e.g. --dtype bf16 --z-dim 100
+DTYPE=f32
+case "$ARGS" in *bf16*) DTYPE=bf16;; *f16*) DTYPE=f16;; esac
+OUT=gpurun_out/refresh_${TAG}
 rm -rf $OUT && mkdir -p $OUT
 export TMPDIR=/tmp
 
-timeout -k 10 300 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
+timeout -k 10 300 python3 bench.py $ARGS > $OUT/bench.json 2> $OUT/bench.err
 echo "bench done"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --no-cpu-baseline $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
 echo "kernel trace done"
-timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline $ARGS > $OUT/pmc_fetch.log 2>&1
 echo "fetch pass done"
-timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline $ARGS > $OUT/pmc_write.log 2>&1
 echo "write pass done"
-timeout -s KILL 120 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $OUT/pmc_mfma -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/pmc_mfma.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $OUT/pmc_mfma -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline $ARGS > $OUT/pmc_mfma.log 2>&1
 echo "mfma pass done"
 
 STATS=$(find $OUT/prof -name '*kernel_stats.csv' | head -1)
@@ -31,5 +35,5 @@ cp $OUT/bench_under_rocprof.json $OUT/final/${TAG}_bench_under_rocprof.json
 cp "$STATS" $OUT/final/${TAG}_bench_kernel_stats.csv
 python3 tools/trace_step.py "$TRACE" --full > $OUT/final/${TAG}_iteration_timeline.txt
 python3 tools/pmc_summary.py "$FETCH" "$WRITE" > $OUT/final/${TAG}_hbm_traffic.json
-python3 tools/mfma_util.py "$MFMA" "$STATS" > $OUT/final/${TAG}_mfma_util.json
+python3 tools/mfma_util.py "$MFMA" "$STATS" "$TRACE" --dtype $DTYPE > $OUT/final/${TAG}_mfma_util.json
 ls -la $OUT/final
