@@ -62,6 +62,7 @@ _PROTOTYPES = {
                                         c_void_p, c_void_p, c_size_t]),
     "gdpso_assessor_create_resnet": (c_int, [C.POINTER(c_void_p), C.POINTER(c_int), c_int, c_int, FloatPP, c_int]),
     "gdpso_assessor_create_resnet_typed": (c_int, [C.POINTER(c_void_p), C.POINTER(c_int), c_int, c_int, FloatPP, c_int, c_int]),
+    "gdpso_assessor_create_alexnet": (c_int, [C.POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, FloatPP, c_int, c_int]),
     "gdpso_assessor_destroy": (None, [c_void_p]),
     "gdpso_assessor_workspace_bytes": (c_size_t, [c_void_p, c_int]),
     "gdpso_assessor_n_class": (c_int, [c_void_p]),

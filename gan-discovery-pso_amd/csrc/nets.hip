@@ -548,6 +548,67 @@ __global__ __launch_bounds__(256) void enc_first_kernel(const float *__restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------
+// First layer of the small "AlexNet" assessor, fused: Conv2d(1 -> C, k x k, padding p, bias) +
+// activation + MaxPool2d(2) (reference src/pso/util_cnn.py:197, 216-219).  One workgroup per
+// image: the zero-padded image sits in LDS, lane = output channel (its k*k weights in registers),
+// the waves take pooled pixels round-robin; each pooled pixel is the maximum of its four
+// activated convolution outputs (the pool drops an odd last row / column like torch's floor mode).
+constexpr int ALEX_MAX_K = 7;
+template <typename E>
+__global__ __launch_bounds__(256) void alex_first_kernel(const float *__restrict__ img, const float *__restrict__ w,
+                                                         const float *__restrict__ bias, int side, int k, int pad, int cout,
+                                                         float slope, E *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int pside = side + 2 * pad, hc = pside - k + 1, hp = hc / 2;
+    const int tid = threadIdx.x, n = blockIdx.x;
+    const float *src = img + (size_t)n * side * side;
+    for (int i = tid; i < pside * pside; i += 256) {
+        const int y = i / pside - pad, x = i % pside - pad;
+        smem[i] = ((unsigned)y < (unsigned)side && (unsigned)x < (unsigned)side) ? src[y * side + x] : 0.f;
+    }
+    __syncthreads();
+    const int lanes = cout < 64 ? cout : 64;  // channels handled side by side (cout is a multiple of 32)
+    const int groups = 256 / lanes;
+    for (int c = tid % lanes; c < cout; c += lanes) {
+        float wreg[ALEX_MAX_K * ALEX_MAX_K];
+#pragma unroll
+        for (int t = 0; t < ALEX_MAX_K * ALEX_MAX_K; ++t) wreg[t] = t < k * k ? w[t * cout + c] : 0.f;
+        const float b = bias[c];
+        for (int p = tid / lanes; p < hp * hp; p += groups) {
+            const int py = p / hp, px = p - py * hp;
+            float m = -INFINITY;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float *base = smem + (2 * py + (q >> 1)) * pside + 2 * px + (q & 1);
+                float acc = 0.f;
+                for (int ky = 0; ky < k; ++ky)
+                    for (int kx = 0; kx < k; ++kx) acc = fmaf(base[ky * pside + kx], wreg[ky * k + kx], acc);
+                acc += b;
+                m = fmaxf(m, fmaxf(acc, 0.f) + slope * fminf(acc, 0.f));
+            }
+            out[((size_t)n * hp * hp + p) * cout + c] = (E)m;
+        }
+    }
+}
+
+// MaxPool2d(2) on an NHWC map (floor mode), four channels per thread.
+template <typename E>
+__global__ __launch_bounds__(256) void pool2_kernel(const E *__restrict__ in, int n, int h, int c, E *__restrict__ out) {
+    const int hp = h / 2, c4 = c / 4;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)n * hp * hp * c4) return;
+    const int cc = (int)(e % c4) * 4;
+    const long pix = e / c4;
+    const int px = (int)(pix % hp), py = (int)((pix / hp) % hp), img = (int)(pix / ((long)hp * hp));
+    const E *base = in + (((size_t)img * h + 2 * py) * h + 2 * px) * c + cc;
+    f32x4 m = load4<E>(base);
+    const f32x4 b = load4<E>(base + c), d = load4<E>(base + (size_t)h * c), f = load4<E>(base + (size_t)h * c + c);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) m[q] = fmaxf(fmaxf(m[q], b[q]), fmaxf(d[q], f[q]));
+    store4<E>(out + (size_t)pix * c + cc, m);
+}
+
 __global__ __launch_bounds__(256) void slice_cols_kernel(const float *__restrict__ in, int ld, int n, int cols,
                                                          float *__restrict__ out) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
@@ -747,6 +808,13 @@ struct gdpso_assessor {
     mutable std::mutex plan_mutex;  // launch plans by batch size, made on first use
     mutable std::map<int, std::shared_ptr<const AssLayout>> plans;
     int dtype;  // DType of the feature maps and of the convolution weights
+    int kind = 0;  // 0: bottleneck ResNet, 1: the 4-convolution "AlexNet"
+    // AlexNet: first layer (Cin = 1) on the vector ALUs, three convolutions, two hidden Linear layers as
+    // 1x1 convolutions; the last Linear + softmax run in head_kernel (fc_w / fc_b, feat_c = 256, feat_hw = 1)
+    const float *alex_w1 = nullptr, *alex_b1 = nullptr;
+    int alex_k = 0, alex_pad = 0, alex_c1 = 32, alex_h[5] = {0, 0, 0, 0, 0};  // map side after each convolution's pool
+    float alex_slope = 0.f;
+    ConvLayer alex_conv[3], alex_fc[2];
     int n_class, side, ho, hp, stem_band, stem_ps;
     const float *stem_w, *stem_scale, *stem_shift;
     std::vector<Bottleneck> blocks;
@@ -760,6 +828,7 @@ struct gdpso_assessor {
 struct AssLayout {
     size_t x, y, t1, t2, sc, splitk, total;
     std::vector<Bottleneck> blocks;
+    ConvLayer alex_conv[3], alex_fc[2];  // AlexNet: the handle's layers with this batch size's launch plan
 };
 namespace {
 std::shared_ptr<const AssLayout> ass_layout(const gdpso_assessor *a, int n) {
@@ -771,6 +840,21 @@ std::shared_ptr<const AssLayout> ass_layout(const gdpso_assessor *a, int n) {
     L.blocks = a->blocks;
     size_t xy = (size_t)n * a->hp * a->hp * 64, t1 = 0, t2 = 0, sc = 0, sk = 0;
     auto out_elems = [&](const ConvLayer &c) { return (size_t)n * c.hout * c.wout * c.cout; };
+    if (a->kind == 1) {
+        xy = (size_t)n * a->alex_h[0] * a->alex_h[0] * a->alex_c1;
+        for (int i = 0; i < 3; ++i) {
+            L.alex_conv[i] = a->alex_conv[i];
+            plan_conv(L.alex_conv[i], n, a->num_cus);
+            xy = std::max(xy, out_elems(L.alex_conv[i]));
+            sk = std::max(sk, conv_splitk_bytes(L.alex_conv[i], n));
+        }
+        for (int i = 0; i < 2; ++i) {
+            L.alex_fc[i] = a->alex_fc[i];
+            plan_conv(L.alex_fc[i], n, a->num_cus);
+            xy = std::max(xy, out_elems(L.alex_fc[i]));
+            sk = std::max(sk, conv_splitk_bytes(L.alex_fc[i], n));
+        }
+    }
     for (auto &b : L.blocks) {
         plan_conv(b.c1, n, a->num_cus);
         plan_conv(b.c2, n, a->num_cus);
@@ -887,6 +971,94 @@ extern "C" int gdpso_assessor_create_resnet_typed(gdpso_assessor **out, const in
     return GDPSO_OK;
 }
 
+// The small "AlexNet" assessor of reference src/pso/util_cnn.py:193-249: four k x k convolutions
+// (1 -> 32 -> 64 -> 128 -> 256, bias, activation, MaxPool2d(2) after each), flatten, Linear(-> 256),
+// Linear(256 -> 256), Linear(256 -> n_class), the activation after the first two (Dropout is inactive
+// in eval mode).
+extern "C" int gdpso_assessor_create_alexnet(gdpso_assessor **out, int n_class, int img_side, int ksize, int pad_same,
+                                             int activation, const float *const *t, int n_tensors, int dtype) {
+    GDPSO_REQUIRE(out && t, "assessor_create_alexnet: null argument");
+    GDPSO_REQUIRE(dtype_ok(dtype), "assessor_create_alexnet: dtype must be GDPSO_DTYPE_F32, _BF16 or _F16");
+    GDPSO_REQUIRE(n_tensors == 14, "assessor_create_alexnet: expected 14 tensors (4 convolutions and 3 Linear layers, weight and bias)");
+    GDPSO_REQUIRE(n_class >= 2 && n_class <= MAX_CLASSES, "assessor_create_alexnet: n_class must be in [2, 64]");
+    GDPSO_REQUIRE(ksize >= 1 && ksize <= ALEX_MAX_K && (ksize % 2 == 1 || !pad_same),
+                  "assessor_create_alexnet: kernel size must be in [1, 7], odd with 'same' padding");
+    GDPSO_REQUIRE(img_side >= 8 && img_side <= 128, "assessor_create_alexnet: img_side must be in [8, 128]");
+    GDPSO_REQUIRE(activation == ACT_RELU || activation == ACT_LEAKY02, "assessor_create_alexnet: activation must be ReLU or LeakyReLU(0.2)");
+    const int pad = pad_same ? (ksize - 1) / 2 : 0;
+    int h = img_side, hs[5];
+    for (int i = 0; i < 4; ++i) {
+        const int hc = h + 2 * pad - ksize + 1;
+        // the error torch raises from the reference's constructor (its dummy forward pass, util_cnn.py:207-209)
+        GDPSO_REQUIRE(hc >= 1, "assessor_create_alexnet: kernel size can't be greater than actual input size (a convolution's input "
+                               "is smaller than its window: with padding 'valid' the image is too small for four convolutions)");
+        h = hc / 2;
+        GDPSO_REQUIRE(h >= 1, "assessor_create_alexnet: a pooled map is empty (image too small)");
+        hs[i] = h;
+    }
+    const int to_linear = 256 * h * h;
+    GDPSO_REQUIRE(to_linear <= 4096, "assessor_create_alexnet: more than 4096 flattened features");
+    auto a = new gdpso_assessor();
+    a->dtype = dtype;
+    a->kind = 1;
+    a->n_class = n_class;
+    a->side = img_side;
+    a->ho = a->hp = a->stem_band = a->stem_ps = 0;
+    a->num_cus = device_cus();
+    a->alex_k = ksize;
+    a->alex_pad = pad;
+    a->alex_slope = activation == ACT_RELU ? 0.f : 0.2f;
+    for (int i = 0; i < 4; ++i) a->alex_h[i] = hs[i];
+    int rc;
+    {
+        // the 16-bit convolution kernels take channels in multiples of 64: the first layer then writes 32
+        // more channels of zeros (zero weights, zero bias), which the second layer's zero-padded weights ignore
+        const int c1 = a->alex_c1 = dtype == DT_F32 ? 32 : 64;
+        std::vector<float> w1((size_t)ksize * ksize * c1, 0.f), b1(c1, 0.f);
+        std::copy(t[1], t[1] + 32, b1.begin());
+        for (int co = 0; co < 32; ++co)
+            for (int p = 0; p < ksize * ksize; ++p) w1[(size_t)p * c1 + co] = t[0][(size_t)co * ksize * ksize + p];
+        if ((rc = a->arena.upload(w1, &a->alex_w1)) || (rc = a->arena.upload(b1, &a->alex_b1))) { delete a; return rc; }
+        const int hc = img_side + 2 * pad - ksize + 1;
+        a->flops = 2.0 * hc * hc * 32 * ksize * ksize;
+    }
+    const int chans[4] = {32, 64, 128, 256};
+    std::vector<float> packed, ones, bias;
+    for (int i = 0; i < 3; ++i) {
+        const int cin = chans[i], cout = chans[i + 1], hin = hs[i];
+        make_conv(a->alex_conv[i], t[2 + 2 * i], cout, cin, ksize, ksize, 1, pad, hin, hin, activation, packed,
+                  dtype == DT_F32 ? 0 : std::max(cin, 64), 0);
+        ones.assign(cout, 1.f);
+        bias.assign(t[3 + 2 * i], t[3 + 2 * i] + cout);
+        if ((rc = upload_conv(a->arena, a->alex_conv[i], packed, ones, bias, dtype))) { delete a; return rc; }
+        a->flops += a->alex_conv[i].flops_nominal;
+    }
+    {
+        // flatten: torch's order is (channel, y, x); the NHWC map is (y, x, channel)
+        std::vector<float> w((size_t)256 * to_linear);
+        for (int o = 0; o < 256; ++o)
+            for (int c = 0; c < 256; ++c)
+                for (int p = 0; p < h * h; ++p) w[(size_t)o * to_linear + (size_t)p * 256 + c] = t[8][(size_t)o * to_linear + (size_t)c * h * h + p];
+        make_conv(a->alex_fc[0], w.data(), 256, to_linear, 1, 1, 1, 0, 1, 1, activation, packed);
+        ones.assign(256, 1.f);
+        bias.assign(t[9], t[9] + 256);
+        if ((rc = upload_conv(a->arena, a->alex_fc[0], packed, ones, bias, dtype))) { delete a; return rc; }
+        make_conv(a->alex_fc[1], t[10], 256, 256, 1, 1, 1, 0, 1, 1, activation, packed);
+        bias.assign(t[11], t[11] + 256);
+        if ((rc = upload_conv(a->arena, a->alex_fc[1], packed, ones, bias, dtype))) { delete a; return rc; }
+        a->flops += a->alex_fc[0].flops_nominal + a->alex_fc[1].flops_nominal;
+    }
+    a->feat_c = 256;
+    a->feat_hw = 1;
+    {
+        std::vector<float> w(t[12], t[12] + (size_t)n_class * 256), b(t[13], t[13] + n_class);
+        if ((rc = a->arena.upload(w, &a->fc_w)) || (rc = a->arena.upload(b, &a->fc_b))) { delete a; return rc; }
+        a->flops += 2.0 * 256 * n_class;
+    }
+    *out = a;
+    return GDPSO_OK;
+}
+
 extern "C" void gdpso_assessor_destroy(gdpso_assessor *a) { delete a; }
 extern "C" int gdpso_assessor_n_class(const gdpso_assessor *a) { return a ? a->n_class : 0; }
 extern "C" double gdpso_assessor_flops_per_image(const gdpso_assessor *a) { return a ? a->flops : 0.0; }
@@ -912,6 +1084,28 @@ static int assessor_forward_impl(const gdpso_assessor *a, void *stream_, int n, 
     char *ws = (char *)workspace;
     void *x = ws + L.x, *y = ws + L.y, *t1 = ws + L.t1, *t2 = ws + L.t2, *sc = ws + L.sc;
     float *sk = (float *)(ws + L.splitk);
+    if (a->kind == 1) {
+        int rc;
+        const int pside = a->side + 2 * a->alex_pad;
+        GDPSO_WITH_DTYPE(a->dtype, hipLaunchKernelGGL(alex_first_kernel<E>, dim3(n), dim3(256), (size_t)pside * pside * sizeof(float), stream,
+                                                      img01, a->alex_w1, a->alex_b1, a->side, a->alex_k, a->alex_pad, a->alex_c1, a->alex_slope,
+                                                      (E *)x));
+        if ((rc = conv_splitk_prepare(stream, sk))) return rc;
+        for (int i = 0; i < 3; ++i) {
+            const ConvLayer &c = L.alex_conv[i];
+            if ((rc = launch_conv(c, stream, n, x, nullptr, y, sk))) return rc;
+            const long quads = (long)n * (c.hout / 2) * (c.hout / 2) * (c.cout / 4);
+            GDPSO_WITH_DTYPE(a->dtype, hipLaunchKernelGGL(pool2_kernel<E>, dim3(ceil_div(quads, 256)), dim3(256), 0, stream, (const E *)y, n,
+                                                          c.hout, c.cout, (E *)x));
+        }
+        if ((rc = launch_conv(L.alex_fc[0], stream, n, x, nullptr, y, sk))) return rc;
+        if ((rc = launch_conv(L.alex_fc[1], stream, n, y, nullptr, x, sk))) return rc;
+        GDPSO_WITH_DTYPE(a->dtype, hipLaunchKernelGGL(head_kernel<E>, dim3(n), dim3(256), 0, stream, (const E *)x, 1, 256, a->fc_w, a->fc_b,
+                                                      a->n_class, logits, fitness, class_index, class_per_image, mode, threshold, eps,
+                                                      mse, w_ass, w_rec));
+        GDPSO_HIP(hipGetLastError());
+        return GDPSO_OK;
+    }
     static const bool stem_mfma = [] {
         const char *e = getenv("GDPSO_STEM_MFMA");
         return e ? e[0] != '0' : true;

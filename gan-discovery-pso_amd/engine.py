@@ -73,6 +73,15 @@ def resnet_tensors(sd):
     return t, dict(depths=tuple(depths), n_class=int(t[-1].shape[0]))
 
 
+def alexnet_tensors(sd):
+    """The 14 arrays gdpso_assessor_create_alexnet wants (reference src/pso/util_cnn.py:197-213)."""
+    names = ["conv1", "conv2", "conv3", "conv4", "fc1", "fc2", "fc3"]
+    t = [_np(sd, f"{n}.{f}") for n in names for f in ("weight", "bias")]
+    if t[0].shape[1] != 1:
+        raise ValueError("only single-channel assessors are supported (data.channel = 1)")
+    return t, dict(kernel=int(t[0].shape[2]), n_class=int(t[12].shape[0]), to_linear=int(t[8].shape[1]))
+
+
 def encoder_tensors(sd, prefix="enc"):
     """reference src/inverter/utils_ae/util_inverter.py:168-174: enc.0, enc.2.0, enc.3.
     ``prefix="encoder"`` reads the encoder of a VectorQuantizedVAE_GAN, which has a
@@ -161,19 +170,38 @@ class PackedGenerator(_Handle):
 
 
 class PackedAssessor(_Handle):
-    """ResNet assessor weights repacked on the device (gdpso_assessor_create_resnet)."""
+    """Assessor weights repacked on the device: a bottleneck ResNet (gdpso_assessor_create_resnet_typed)
+    or, when the state dict has the reference AlexNet's keys, that network
+    (gdpso_assessor_create_alexnet; ``cnn_args`` = the reference's dict with 'padding' and
+    'cnn_activation', default padding 'same' and LeakyReLU)."""
     _destroy = "gdpso_assessor_destroy"
 
-    def __init__(self, model, device, img_side=28, dtype="f32"):
+    def __init__(self, model, device, img_side=28, dtype="f32", cnn_args=None):
         super().__init__()
         self.device = _device_guard(device)
         self.dtype = dtype
-        tensors, self.meta = resnet_tensors(_state_dict_of(model))
-        arr, keep = _lib.host_float_pointers(tensors)
-        depths = (C.c_int * 4)(*self.meta["depths"])
+        sd = _state_dict_of(model)
+        if cnn_args is None:
+            cnn_args = getattr(model, "cnn_args", None)
         with torch.cuda.device(self.device):
-            check(_lib.lib().gdpso_assessor_create_resnet_typed(C.byref(self.h), depths, self.meta["n_class"], img_side, arr,
-                                                                len(keep), _dtype_code(dtype)))
+            if "fc1.weight" in sd and "conv4.weight" in sd:
+                tensors, self.meta = alexnet_tensors(sd)
+                arr, keep = _lib.host_float_pointers(tensors)
+                args = dict(padding="same", cnn_activation="LeakyReLU")
+                args.update(cnn_args or {})
+                if args["padding"] not in ("same", "valid"):
+                    raise ValueError(f"padding {args['padding']!r}: 'same' or 'valid'")
+                act = {"ReLU": 1, "LeakyReLU": 2}.get(args["cnn_activation"])
+                if act is None:
+                    raise ValueError(args["cnn_activation"])  # the reference's get_activation error (util_cnn.py:54)
+                check(_lib.lib().gdpso_assessor_create_alexnet(C.byref(self.h), self.meta["n_class"], img_side, self.meta["kernel"],
+                                                               int(args["padding"] == "same"), act, arr, len(keep), _dtype_code(dtype)))
+            else:
+                tensors, self.meta = resnet_tensors(sd)
+                arr, keep = _lib.host_float_pointers(tensors)
+                depths = (C.c_int * 4)(*self.meta["depths"])
+                check(_lib.lib().gdpso_assessor_create_resnet_typed(C.byref(self.h), depths, self.meta["n_class"], img_side, arr,
+                                                                    len(keep), _dtype_code(dtype)))
         self.n_class = self.meta["n_class"]
         self.side = img_side
         self.flops_per_image = _lib.lib().gdpso_assessor_flops_per_image(self.h)

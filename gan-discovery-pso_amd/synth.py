@@ -11,6 +11,7 @@ reference modules, so they load into either implementation:
 * generator  -- reference ``src/utils/util_dcgan.py:128-149``
 * ResNet     -- reference ``src/pso/util_cnn.py:81-190``
 * encoder    -- reference ``src/inverter/utils_ae/util_inverter.py:164-184``
+* AlexNet    -- reference ``src/pso/util_cnn.py:193-249``
 
 Two styles:
 
@@ -112,6 +113,36 @@ def resnet_state(model_name: str = "ResNet50", image_channels: int = 1, n_class:
         bound = 1.0 / np.sqrt(2048.0)
         sd["fc.weight"] = rs.uniform(-bound, bound, (n_class, 2048)).astype(np.float32)
         sd["fc.bias"] = rs.uniform(-bound, bound, (n_class,)).astype(np.float32)
+    return sd
+
+
+def alexnet_to_linear(img_size: int, kernel: int = 3, padding: str = "same") -> int:
+    """Flattened feature count of the 4-convolution "AlexNet" (reference util_cnn.py:207-209, 233-234)."""
+    pad = (kernel - 1) // 2 if padding == "same" else 0
+    h = img_size
+    for _ in range(4):
+        h = (h + 2 * pad - kernel + 1) // 2
+    return 256 * h * h
+
+
+def alexnet_state(n_class: int = 8, *, kernel: int = 3, img_size: int = 28, padding: str = "same", seed: int = 5,
+                  logit_gain: float = 4.0) -> dict:
+    """State dict of the small "AlexNet" assessor (reference util_cnn.py:197-213): conv1..conv4 with bias,
+    fc1 (flattened -> 256), fc2 (256 -> 256), fc3 (256 -> n_class)."""
+    rs = np.random.RandomState(seed)
+    sd: dict = {}
+    cin = 1
+    for i, cout in enumerate((32, 64, 128, 256), start=1):
+        sd[f"conv{i}.weight"] = _normal(rs, (cout, cin, kernel, kernel), np.sqrt(2.0 / (cin * kernel * kernel)))
+        sd[f"conv{i}.bias"] = _normal(rs, (cout,), 0.1)
+        cin = cout
+    k = alexnet_to_linear(img_size, kernel, padding)
+    sd["fc1.weight"] = _normal(rs, (256, k), np.sqrt(2.0 / k))
+    sd["fc1.bias"] = _normal(rs, (256,), 0.1)
+    sd["fc2.weight"] = _normal(rs, (256, 256), np.sqrt(2.0 / 256))
+    sd["fc2.bias"] = _normal(rs, (256,), 0.1)
+    sd["fc3.weight"] = _normal(rs, (n_class, 256), logit_gain / np.sqrt(256.0))
+    sd["fc3.bias"] = _normal(rs, (n_class,), 0.1)
     return sd
 
 

@@ -114,6 +114,16 @@ int gdpso_assessor_create_resnet(gdpso_assessor **out, const int depths[4], int 
  * fp32.  gdpso_assessor_create_resnet is the GDPSO_DTYPE_F32 case. */
 int gdpso_assessor_create_resnet_typed(gdpso_assessor **out, const int depths[4], int n_class, int img_side,
                                        const float *const *tensors, int n_tensors, int dtype);
+/* Replaces AlexNet.forward, reference src/pso/util_cnn.py:193-249 (get_cnn("AlexNet", ...), :25-26):
+ * four ksize x ksize convolutions 1 -> 32 -> 64 -> 128 -> 256 with bias, each followed by the
+ * activation and MaxPool2d(2); flatten; Linear(-> 256), Linear(256 -> 256), Linear(256 -> n_class)
+ * with the activation after the first two (Dropout is inactive in eval mode).  pad_same: cnn_args
+ * padding 'same' (else 'valid'); activation: 1 ReLU, 2 LeakyReLU(0.2) (cnn_args cnn_activation).
+ * `tensors` (HOST) fp32, PyTorch layout: conv1..conv4 .weight/.bias, fc1..fc3 .weight/.bias (14).
+ * Fails like the reference's constructor when a convolution's input is smaller than its window
+ * (padding 'valid' at 28x28).  The handle is used through gdpso_assessor_forward like a ResNet's. */
+int gdpso_assessor_create_alexnet(gdpso_assessor **out, int n_class, int img_side, int ksize, int pad_same, int activation,
+                                  const float *const *tensors, int n_tensors, int dtype);
 void gdpso_assessor_destroy(gdpso_assessor *a);
 size_t gdpso_assessor_workspace_bytes(const gdpso_assessor *a, int n);
 int gdpso_assessor_n_class(const gdpso_assessor *a);

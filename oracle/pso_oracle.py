@@ -103,6 +103,20 @@ def resnet_forward(sd: dict, x: torch.Tensor, stages: bool = False):
     return logits
 
 
+def alexnet_forward(sd: dict, x: torch.Tensor, padding: str = "same", activation: str = "LeakyReLU") -> torch.Tensor:
+    """x [B,1,H,W] -> logits [B,n_class].  Follows reference src/pso/util_cnn.py:216-249: four times
+    (convolution with bias, activation, MaxPool2d(2)), flatten in (channel, y, x) order, fc1 + activation,
+    fc2 + activation, fc3; Dropout is inactive in eval mode.  ``activation``: "LeakyReLU" (slope 0.2,
+    :48-50) or "ReLU"."""
+    act = (lambda v: F.leaky_relu(v, 0.2)) if activation == "LeakyReLU" else F.relu
+    for i in (1, 2, 3, 4):
+        x = F.max_pool2d(act(F.conv2d(x, sd[f"conv{i}.weight"], sd[f"conv{i}.bias"], padding=padding)), 2)
+    x = x.contiguous().view(x.shape[0], -1)
+    x = act(F.linear(x, sd["fc1.weight"], sd["fc1.bias"]))
+    x = act(F.linear(x, sd["fc2.weight"], sd["fc2.bias"]))
+    return F.linear(x, sd["fc3.weight"], sd["fc3.bias"])
+
+
 def encoder_forward(sd: dict, x: torch.Tensor) -> torch.Tensor:
     """img [B,C,28,28] -> latent [B,Z,1,1].  Reference util_inverter.py:168-184."""
     x = F.leaky_relu(F.conv2d(x, sd["enc.0.weight"], sd["enc.0.bias"], 2, 1), 0.2)
@@ -182,8 +196,9 @@ class Fitness:
     """
 
     def __init__(self, gen_sd, cnn_sd, class_index, mode="optimize_out_training", threshold=0.0,
-                 eps=0.1, targets=None, w_ass=1.0, w_rec=1.0):
+                 eps=0.1, targets=None, w_ass=1.0, w_rec=1.0, cnn_args=None):
         self.gen_sd, self.cnn_sd = gen_sd, cnn_sd
+        self.cnn_args = cnn_args  # given: the assessor is the "AlexNet" (padding, cnn_activation)
         self.class_index, self.mode = class_index, mode
         self.threshold, self.eps = threshold, eps
         self.targets, self.w_ass, self.w_rec = targets, w_ass, w_rec
@@ -198,7 +213,10 @@ class Fitness:
         """pos [B,D] -> fitness [B] float32 (particles ``first`` .. ``first+B-1`` of the swarm)."""
         with torch.no_grad():
             img01, img = self.images(pos)
-            logits = resnet_forward(self.cnn_sd, img01)
+            if self.cnn_args is not None:
+                logits = alexnet_forward(self.cnn_sd, img01, self.cnn_args["padding"], self.cnn_args["cnn_activation"])
+            else:
+                logits = resnet_forward(self.cnn_sd, img01)
             f = fitness_from_logits(logits, self.class_index, self.mode, self.threshold, self.eps)
             f = f.numpy().astype(np.float32)
             if self.targets is not None:

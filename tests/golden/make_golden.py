@@ -322,6 +322,45 @@ def fx_vq(ref):
     save("vq", **out)
 
 
+def fx_alexnet(ref):
+    """The small "AlexNet" assessor (reference util_cnn.py:193-249): logits at 28x28 with padding 'same'
+    (LeakyReLU) and at 64x64 with padding 'valid' (ReLU), fitness of generated images through
+    Discovery, a short swarm run, and the constructor's failure with the YAML's padding 'valid' at 28x28."""
+    out = {}
+    rs = np.random.RandomState(91)
+    iid = [0, 2, 3, 4, 6, 7, 8, 9]
+    args28 = {"kernel": 3, "padding": "same", "cnn_activation": "LeakyReLU"}
+    args64 = {"kernel": 3, "padding": "valid", "cnn_activation": "ReLU"}
+    sd28 = synth.alexnet_state(8, kernel=3, img_size=28, padding="same", seed=51)
+    sd64 = synth.alexnet_state(8, kernel=3, img_size=64, padding="valid", seed=52)
+    cnn28 = ref.util_cnn.get_cnn("AlexNet", 1, iid, 8, img_dim=28, cnn_args=args28)
+    cnn28.load_state_dict(synth.to_torch(sd28)); cnn28.eval()
+    cnn64 = ref.util_cnn.get_cnn("AlexNet", 1, iid, 8, img_dim=64, cnn_args=args64)
+    cnn64.load_state_dict(synth.to_torch(sd64)); cnn64.eval()
+    x28 = rs.uniform(0, 1, (5, 1, 28, 28)).astype(np.float32)
+    x64 = rs.uniform(0, 1, (3, 1, 64, 64)).astype(np.float32)
+    with torch.no_grad():
+        out.update(x28=x28, logits28=cnn28(torch.from_numpy(x28)).numpy(), x64=x64, logits64=cnn64(torch.from_numpy(x64)).numpy())
+    out.update(to_linear28=cnn28._to_linear, to_linear64=cnn64._to_linear, seed28=51, seed64=52,
+               ck28=synth.checksum(sd28), ck64=synth.checksum(sd64))
+    try:
+        ref.util_cnn.get_cnn("AlexNet", 1, iid, 8, img_dim=28, cnn_args={"kernel": 3, "padding": "valid", "cnn_activation": "LeakyReLU"})
+        out["valid28_error"] = "none"
+    except Exception as e:  # noqa: BLE001 - the type is what is recorded
+        out["valid28_error"] = type(e).__name__
+    # through Discovery with the Z=10 generator, and a short swarm
+    gsd = synth.generator_state(10, 1, 64, seed=11)
+    gen = ref.util_dcgan.Generator(z_dim=10, channels_img=1, features_g=64)
+    gen.load_state_dict(synth.to_torch(gsd)); gen.eval()
+    disc = ref.util_discovery.Discovery(2, gen, cnn28, torch.device("cpu"), iid_classes=iid, obj_fun_threshold=0.)
+    z = rs.standard_normal((6, 10))
+    out.update(z=z, fitness=np.array([np.asarray(disc.fitness(dim_space=10, pos=z[k])[0]).reshape(-1)[0] for k in range(6)], np.float32),
+               label=2, iid=np.array(iid), gen_seed=11)
+    sw = run_reference_swarm(ref, disc, 8, 6, 10, (0.73, 1.496, 1.496), False, False, 1e-5, 13)
+    out.update({"sw_" + k: v for k, v in sw.items()})
+    save("alexnet", **out)
+
+
 FIXTURES = {
     "layers": lambda r: fx_layers(r),
     "swarm_n8_t5_z10": lambda r: fx_swarm(r, "swarm_n8_t5_z10", 8, 5, 10, (0.73, 1.496, 1.496), False, False, 42),
@@ -335,6 +374,7 @@ FIXTURES = {
     "vq": lambda r: fx_vq(r),
     "toy_sphere": lambda r: fx_toy(r),
     "assessor_shapes": lambda r: fx_big_input(r),
+    "alexnet": lambda r: fx_alexnet(r),
 }
 
 

@@ -185,3 +185,26 @@ def test_vq(oracle, synth):
         np.testing.assert_array_equal(g["B_emb_latents"], g["B_idx"])
         np.testing.assert_array_equal(g["B_emb_st"], np.transpose(g["B_codes"], (0, 3, 1, 2)))
         np.testing.assert_array_equal(g["B_emb_bar"], g["B_emb_st"])
+
+
+def test_alexnet(oracle, synth):
+    """The small "AlexNet" assessor (reference util_cnn.py:193-249): logits at 28x28 / 'same' / LeakyReLU
+    and 64x64 / 'valid' / ReLU, fitness through the generator, and a short swarm, all from the
+    reference's own classes."""
+    g = load_golden("alexnet")
+    sd28 = synth.to_torch(synth.alexnet_state(8, kernel=3, img_size=28, padding="same", seed=int(g["seed28"])))
+    sd64 = synth.to_torch(synth.alexnet_state(8, kernel=3, img_size=64, padding="valid", seed=int(g["seed64"])))
+    assert synth.checksum({k: v.numpy() for k, v in sd28.items()}) == str(g["ck28"])
+    assert sd28["fc1.weight"].shape[1] == int(g["to_linear28"]) == 256 and sd64["fc1.weight"].shape[1] == int(g["to_linear64"]) == 1024
+    with torch.no_grad():
+        np.testing.assert_allclose(oracle.alexnet_forward(sd28, torch.from_numpy(g["x28"])).numpy(), g["logits28"], atol=1e-5)
+        np.testing.assert_allclose(oracle.alexnet_forward(sd64, torch.from_numpy(g["x64"]), "valid", "ReLU").numpy(), g["logits64"], atol=1e-5)
+    assert str(g["valid28_error"]) == "RuntimeError"
+    gsd = synth.to_torch(synth.generator_state(10, 1, 64, seed=int(g["gen_seed"])))
+    ci = sorted(g["iid"].tolist()).index(int(g["label"]))
+    fit = oracle.Fitness(gsd, sd28, ci, cnn_args={"padding": "same", "cnn_activation": "LeakyReLU"})
+    np.testing.assert_allclose(fit(g["z"]), g["fitness"], atol=1e-5)  # one batch of six here, six batches of one there
+    ref = oracle.run_swarm(fit, g["sw_pos"][0], g["sw_vel"][0], int(g["sw_t"]), *[float(v) for v in g["sw_w"]], early_stopping=False,
+                           rand=g["sw_rand"], batch=1)
+    np.testing.assert_allclose(np.stack(ref["fitness"]), g["sw_fitness"], atol=1e-6)
+    np.testing.assert_array_equal(np.stack(ref["pos"]), g["sw_pos"])
