@@ -12,7 +12,10 @@ from parity_utils import first_ambiguous_iteration
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4  # fp32 outputs within 1e-4 of the reference CPU path
-SWARMS = ["swarm_n8_t5_z10", "swarm_n64_t50_z10", "swarm_n16_t30_z100_sched_es", "swarm_n12_t40_z10_es"]
+SWARMS = ["swarm_n8_t5_z10", "swarm_n64_t50_z10", "swarm_n16_t30_z100_sched_es", "swarm_n12_t40_z10_es",
+          "swarm_n64_t50_z10_margin"]
+# iterations a recorded run can be followed end to end (every decision clear of fp32 noise), at least
+MIN_SAFE = {"swarm_n64_t50_z10_margin": 35}
 
 
 @pytest.fixture(scope="module")
@@ -78,7 +81,7 @@ def test_trajectory(mods, synth, name):
     res = sw.results
     iters = g["fitness"].shape[0]
     safe = first_ambiguous_iteration(g["fitness"], 2e-5)
-    assert safe >= min(iters, 5)
+    assert safe >= min(iters, MIN_SAFE.get(name, 5))
     np.testing.assert_array_equal(res["hist_pos"][0], g["pos"][0])  # same RNG consumption
     np.testing.assert_array_equal(res["hist_vel"][0], g["vel"][0])
     np.testing.assert_allclose(res["fitness"][:safe], g["fitness"][:safe], atol=TOL)

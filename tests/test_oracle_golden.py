@@ -42,7 +42,7 @@ def test_layers(oracle, synth):
 
 
 @pytest.mark.parametrize("name", ["swarm_n8_t5_z10", "swarm_n64_t50_z10", "swarm_n16_t30_z100_sched_es",
-                                  "swarm_n12_t40_z10_es"])
+                                  "swarm_n12_t40_z10_es", "swarm_n64_t50_z10_margin"])
 def test_swarm_trajectory(oracle, synth, name):
     """Same seeds in -> the oracle reproduces the reference's whole trajectory."""
     g = load_golden(name)
@@ -63,7 +63,7 @@ def test_swarm_trajectory(oracle, synth, name):
         # batched CPU convolutions round differently from batch-1 ones (~5e-6 on the fitness):
         # the trajectory is comparable while every decision has a larger margin than that
         safe = first_ambiguous_iteration(g["fitness"], 5e-5)
-        assert safe >= 6
+        assert safe >= (35 if name.endswith("margin") else 6)
         np.testing.assert_allclose(np.stack(out["fitness"])[:safe], g["fitness"][:safe], atol=TOL)
         np.testing.assert_allclose(np.stack(out["pos"])[:safe + 1], g["pos"][:safe + 1], rtol=1e-9, atol=1e-9)
         # and per step everywhere: the reference's positions in, the reference's fitness out
