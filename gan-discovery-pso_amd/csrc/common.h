@@ -139,6 +139,28 @@ int launch_conv_pair(const ConvLayer &La, const ConvLayer &Lb, hipStream_t strea
 int launch_conv_then_1x1(const ConvLayer &La, const ConvLayer &Lb, hipStream_t stream, int n_images, const void *in,
                          void *mid, const void *res, void *out, float *splitk_ws);
 
+// A run of dependent layers in one persistent launch (conv_gemm.hip: conv_chain_kernel).  Offsets are
+// bytes into the workspace the chain is launched on.
+struct ConvChain;
+// A buffer a chain reads or writes: byte offset in the workspace and, for buffers the chain writes,
+// their size: every share of the images keeps a fixed slice (size / shares) of it, whatever the layer,
+// which must hold a share's bytes of every layer stored there.  bytes 0 = standard NHWC layout (the
+// chain's input, read only, and its final output, written once).
+struct ChainBuf {
+    size_t offset, bytes;
+};
+bool chain_enabled();
+int chain_teams();         // teams per XCD a new chain should have (1 or 2)
+size_t chain_ctl_bytes();  // control block inside the workspace (zeroed by launch_chain)
+ConvChain *chain_new(int n_images, int nteams);
+void chain_free(ConvChain *c);
+int chain_steps(const ConvChain *c);
+bool chain_layer_ok(const ConvLayer &L, int n_images, int nteams);
+int chain_add(ConvChain *c, const ConvLayer *La, const ChainBuf &in, const ChainBuf *res, const ChainBuf &out_a,
+              const ConvLayer *Lb = nullptr, const ChainBuf *out_b = nullptr);
+int chain_finish(ConvChain *c, size_t ctl_off);
+int launch_chain(const ConvChain *c, hipStream_t stream, void *workspace);
+
 // host-side helpers (pack.cpp)
 struct DeviceArena {
     std::vector<void *> blocks;

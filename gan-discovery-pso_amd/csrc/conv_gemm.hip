@@ -33,6 +33,8 @@
 #include <hip/hip_ext.h>
 
 #include <cstdlib>
+#include <cstring>
+#include <deque>
 
 #include "common.h"
 
@@ -87,6 +89,59 @@ struct FuseArgs {  // fp32 instantiation only
     float *out;
     int cout, act;
 };
+
+// What a tile of a chain waits for before it reads activations: the first `count` words of `flags`
+// (one per member of the team, null: nothing) all having reached `target`.  `status` is the chain's
+// abort word: a wait that runs out of patience sets it and every later wait of the launch returns at
+// once, so a broken chain ends with wrong results and a raised flag instead of hanging the GPU.
+struct ChainWait {
+    const unsigned *flags = nullptr;
+    unsigned target = 0;
+    int count = 0;
+    unsigned *status = nullptr;
+#ifdef GDPSO_STAMPS
+    unsigned long long *stamp = nullptr;  // diagnostic build: where to note the time the wait ended
+#endif
+};
+constexpr unsigned CHAIN_SPIN_LIMIT = 4000000;  // polls (each an L2 round trip): seconds
+__device__ unsigned g_chain_aborts = 0;         // chains that gave up waiting since the library was loaded
+
+__device__ __forceinline__ void chain_abort(unsigned *status, unsigned bit) {
+    if (__hip_atomic_fetch_or(status, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+        __hip_atomic_fetch_add(&g_chain_aborts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The first wave polls, one member's word per lane (agent-scope atomic loads: never served from the
+// CU's L1), then the workgroup meets at a barrier.  No read-modify-write anywhere: arrivals at one
+// counter serialise in the L2 (64 of them cost 1.6 us, measured by tools/micro/xcd_barrier.hip), plain
+// stores to words of their own do not.  The memory clobber keeps the activation loads behind the wait.
+__device__ __forceinline__ void chain_wait(const ChainWait &w, int tid) {
+    if (w.flags == nullptr) return;
+    if (tid < 64) {
+        unsigned spins = 0;
+        for (int base = 0; base < w.count; base += 64) {
+            for (;;) {
+                const int m = base + tid;
+                const unsigned f = m < w.count ? __hip_atomic_load(w.flags + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+                if (__all((int)(f >= w.target))) break;
+                ++spins;
+                if ((spins & 255u) == 0) {
+                    const unsigned st = __hip_atomic_load(w.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__any((int)(st != 0 || spins > CHAIN_SPIN_LIMIT))) {
+                        if (tid == 0) chain_abort(w.status, 1u);
+                        base = w.count;
+                        break;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    asm volatile("" ::: "memory");
+#ifdef GDPSO_STAMPS
+    if (w.stamp && tid == 0) *w.stamp = __builtin_amdgcn_s_memrealtime();
+#endif
+}
 
 // What a workgroup needs to know about its phase (all wave-uniform).
 struct PhaseInfo {
@@ -144,7 +199,7 @@ struct StorePlan {
     f32x4 rres[PREFETCH_RES ? PASSES : 1];
 };
 
-template <typename E, int BM, int BN>
+template <typename E, int BM, int BN, bool CHAIN = false>
 __device__ __forceinline__ void conv_store_plan(const ConvKArgs &a, int tid, int m0, int n0, const PhaseInfo &P,
                                                 StorePlan<BM, BN> &sp) {
     using Plan = StorePlan<BM, BN>;
@@ -167,10 +222,22 @@ __device__ __forceinline__ void conv_store_plan(const ConvKArgs &a, int tid, int
     if constexpr (Plan::PREFETCH_RES) {
         // rows past M read the first row's residual (any valid address; the value is not used)
         const bool want = a.splits == 1 && a.res != nullptr;
+        if constexpr (CHAIN) {
+            // written earlier in this launch by a workgroup of the same XCD: read past the L1 (sc1)
+            static_assert(is_f32<E>(), "chains run in fp32");
+            const __amdgpu_buffer_rsrc_t rsrc_res = __builtin_amdgcn_make_buffer_rsrc((void *)a.res, 0, (int)(a.slab * 4), 0x00020000);
 #pragma unroll
-        for (int pass = 0; pass < Plan::PASSES; ++pass) {
-            sp.rres[pass] = 0.f;
-            if (want) sp.rres[pass] = load4<E>((const E *)a.res + (sp.off[pass] < 0 ? col : sp.off[pass]));
+            for (int pass = 0; pass < Plan::PASSES; ++pass) {
+                sp.rres[pass] = 0.f;
+                if (want)
+                    sp.rres[pass] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_res, (sp.off[pass] < 0 ? col : sp.off[pass]) * 4, 0, 16 /* sc1 */));
+            }
+        } else {
+#pragma unroll
+            for (int pass = 0; pass < Plan::PASSES; ++pass) {
+                sp.rres[pass] = 0.f;
+                if (want) sp.rres[pass] = load4<E>((const E *)a.res + (sp.off[pass] < 0 ? col : sp.off[pass]));
+            }
         }
     }
 }
@@ -296,8 +363,14 @@ __device__ __forceinline__ f32x16 mfma16(const f32x4 &a, const f32x4 &b, const f
 // second half of every K-tile; the two halves are added through LDS before the epilogue.  That
 // shape doubles the number of workgroups of a small-M layer without split-K slabs.
 // E: element type of activations and weights (float, bf16_t, f16_t); BKT: elements per K-tile.
-template <typename E, int BM, int BN, int BKT, int KW, bool FUSE = false>
-__device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, float *lds, const FuseArgs *fuse = nullptr) {
+// CHAIN: the tile is one of many that a persistent workgroup of conv_chain_kernel walks through.  `xcd` is
+// then the share of the images the workgroup's team owns and `slot` the tile's index inside it; the
+// activations (A operand, residual) were written earlier in the same launch by workgroups on the same
+// XCD and are read with sc1 loads, which miss the CU's L1 and hit the XCD's L2; the tile's first
+// activation load waits for `wait` (weights, tables and arguments are fetched ahead of the wait).
+template <typename E, int BM, int BN, int BKT, int KW, bool FUSE = false, bool CHAIN = false>
+__device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int slot, float *lds, const FuseArgs *fuse = nullptr,
+                                          const ChainWait wait = ChainWait{}) {
     constexpr int VEC = vec_of<E>();  // elements per 16-byte vector
     constexpr bool F32 = is_f32<E>();
     static_assert(!FUSE || (BM == 64 && BN == 64 && KW == 1 && F32), "the fused tail is written for the fp32 64x64 tile");
@@ -335,8 +408,7 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
                  GDPSO_W(7), GDPSO_W(8), GDPSO_W(9), GDPSO_W(10), GDPSO_W(11), GDPSO_W(12), GDPSO_W(13), GDPSO_W(14),
                  GDPSO_W(15));
 #undef GDPSO_W
-    const int xcd = bx & 7;
-    int slot = bx >> 3;
+    const int tile = slot * 8 + xcd;  // the launch's workgroup index (split-K arrival counter)
     // An XCD deals its workgroups round-robin to its CUs: with two per CU and phases in order of
     // decreasing cost, CU i would get the i-th heaviest and the (i + CUs)-th heaviest.  Dealing the
     // second round from the light end pairs heavy with light.
@@ -359,11 +431,10 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
     }
     const int per_xcd = (int)(sel & 0xffffffu) - base;
     const int idx = xcd * per_xcd + (slot - base);
-    if (idx >= 8 * per_xcd - (int)(sel >> 24)) return;
-    const int tile = bx;
+    if (!CHAIN && idx >= 8 * per_xcd - (int)(sel >> 24)) return;  // (a chain's shares hold whole tiles only)
     const int tml = fast_div(idx, a.tiles_n_mul, a.tiles_n_shift), tn = idx - tml * a.tiles_n;
     const int m0 = tml * BM, n0 = tn * BN;
-    const int sp = blockIdx.z;
+    const int sp = CHAIN ? 0 : blockIdx.z;
     // The table is read through the constant address space: that keeps its loads scalar whatever
     // else the kernel does (behind an asm statement or a store the compiler assumes that global
     // memory may have changed, and falls back to vector loads).
@@ -416,6 +487,13 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
     // dy | dx << 8 | (position of the tap in the weight rows) << 16.
     const E *aptr[PA], *bptr[PB];
     const E *brow[PB];
+    // CHAIN: the A operand goes through buffer loads (byte offsets from a.in; the sc1 bit makes them miss
+    // the L1); rows in the padding point past the end of the buffer, where a buffer load returns zeros
+    unsigned aoff[PA];
+    constexpr unsigned A_OUTSIDE = 0xC0000000u;  // stays out of range however far the K loop advances it
+    __amdgpu_buffer_rsrc_t rsrc_in;
+    if constexpr (CHAIN)
+        rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, a.n_images * a.hin * a.win * a.cin * (int)sizeof(E), 0x00020000);
 #pragma unroll
     for (int p = 0; p < PB; ++p) brow[p] = wt + ((n0 + lrow + RP * p) * wstride + lcol);  // 32-bit offsets: see conv_args
     int tap = a.splits == 1 ? 0 : kbeg / a.cin, ci0 = kbeg - tap * a.cin;
@@ -427,8 +505,11 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
         _Pragma("unroll") for (int p = 0; p < PA; ++p) {                                                        \
             const int iy = a_iy0[p] + dy_, ix = a_ix0[p] + dx_;                                                 \
             const bool ok = a_ok[p] && (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;        \
-            aptr[p] = ok ? in + ((a_img[p] + iy * a.win + ix) * a.cin + (CI) + lcol)                            \
-                         : (const E *)g_zero_page + (CI) + lcol;                                                \
+            if constexpr (CHAIN)                                                                                \
+                aoff[p] = ok ? (unsigned)((a_img[p] + iy * a.win + ix) * a.cin + (CI) + lcol) * (unsigned)sizeof(E) : A_OUTSIDE; \
+            else                                                                                                \
+                aptr[p] = ok ? in + ((a_img[p] + iy * a.win + ix) * a.cin + (CI) + lcol)                        \
+                             : (const E *)g_zero_page + (CI) + lcol;                                            \
         }                                                                                                       \
         _Pragma("unroll") for (int p = 0; p < PB; ++p) bptr[p] = brow[p] + wk_;                                 \
     }
@@ -443,14 +524,32 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
     f32x4 ra[NSET][PA], rb[NSET][PB];
     // A K-tile's loads (straight-line, so that a K-step can interleave them with its MFMAs) and,
     // separately, the move of the gather pointers to the next K-tile (which branches at a tap change).
+#define GDPSO_GISSUE_A(S)                                                                                       \
+    {                                                                                                           \
+        _Pragma("unroll") for (int p = 0; p < PA; ++p) {                                                        \
+            if constexpr (CHAIN)                                                                                \
+                ra[S][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, (int)aoff[p], 0, 16 /* sc1 */)); \
+            else                                                                                                \
+                ra[S][p] = *(global_f32x4_ptr)aptr[p];                                                          \
+        }                                                                                                       \
+    }
+#define GDPSO_GISSUE_B(S)                                                                                       \
+    {                                                                                                           \
+        _Pragma("unroll") for (int p = 0; p < PB; ++p) rb[S][p] = *(global_f32x4_ptr)bptr[p];                    \
+    }
 #define GDPSO_GISSUE(S)                                                                                         \
     {                                                                                                           \
-        _Pragma("unroll") for (int p = 0; p < PA; ++p) ra[S][p] = *(global_f32x4_ptr)aptr[p];                    \
-        _Pragma("unroll") for (int p = 0; p < PB; ++p) rb[S][p] = *(global_f32x4_ptr)bptr[p];                    \
+        GDPSO_GISSUE_A(S)                                                                                       \
+        GDPSO_GISSUE_B(S)                                                                                       \
     }
 #define GDPSO_GADVANCE()                                                                                        \
     {                                                                                                           \
-        _Pragma("unroll") for (int p = 0; p < PA; ++p) aptr[p] += BKT;                                          \
+        _Pragma("unroll") for (int p = 0; p < PA; ++p) {                                                        \
+            if constexpr (CHAIN)                                                                                \
+                aoff[p] += BKT * (unsigned)sizeof(E);                                                           \
+            else                                                                                                \
+                aptr[p] += BKT;                                                                                 \
+        }                                                                                                       \
         _Pragma("unroll") for (int p = 0; p < PB; ++p) bptr[p] += BKT;                                          \
         ci0 += BKT;                                                                                             \
         if (ci0 == a.cin) {                                                                                     \
@@ -488,7 +587,15 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
     const int nk = kbeg < kend ? (kend - kbeg) / BKT : 0;  // K-tiles of this workgroup
     if (nk > 0) {
         GDPSO_SET_TAP(ci0, tap == 0 ? tap0_packed : tab[PHASE_HDR + tap])
-        GDPSO_GLOAD(0)
+        if constexpr (CHAIN) {
+            // weights first; the activations only once the layer that writes them has finished in this share
+            GDPSO_GISSUE_B(0)
+            chain_wait(wait, tid);
+            GDPSO_GISSUE_A(0)
+            GDPSO_GADVANCE()
+        } else {
+            GDPSO_GLOAD(0)
+        }
 #ifdef GDPSO_STAMPS
         GDPSO_STAMP(9)  // first loads issued
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -619,6 +726,8 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
 #undef GDPSO_SGB
 #undef GDPSO_SGB4
 #undef GDPSO_GISSUE
+#undef GDPSO_GISSUE_A
+#undef GDPSO_GISSUE_B
 #undef GDPSO_GADVANCE
 #undef GDPSO_DBG
 #undef GDPSO_SET_TAP
@@ -706,7 +815,8 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
     constexpr int LDC = BN + 4;
     float *sC = lds;
     StorePlan<BM, BN> plan;
-    conv_store_plan<E, BM, BN>(a, tid, m0, n0, P, plan);
+    static_assert(!CHAIN || StorePlan<BM, BN>::PREFETCH_RES, "a chain's residual is read by conv_store_plan only");
+    conv_store_plan<E, BM, BN, CHAIN>(a, tid, m0, n0, P, plan);
     if (KW == 1) {
 #pragma unroll
         for (int i = 0; i < WM; ++i)
@@ -736,14 +846,14 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int bx, floa
 template <typename E, int BM, int BN, int BKB, int KW>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * (BKB / 4 + 4)];
-    conv_tile<E, BM, BN, BKB / (int)sizeof(E), KW>(a, blockIdx.x, lds);
+    conv_tile<E, BM, BN, BKB / (int)sizeof(E), KW>(a, blockIdx.x & 7, blockIdx.x >> 3, lds);
 }
 
 // A convolution with 64 output channels followed by a 1x1 convolution, one launch: conv2 + conv3
 // of the first-stage bottleneck blocks.  The intermediate never leaves the workgroup.
 __global__ __launch_bounds__(256, 2) void conv_gemm_fused_kernel(const ConvKArgs a, const FuseArgs f) {
     __shared__ __attribute__((aligned(16))) float lds[3 * 64 * 68];
-    conv_tile<float, 64, 64, 32, 1, true>(a, blockIdx.x, lds, &f);
+    conv_tile<float, 64, 64, 32, 1, true>(a, blockIdx.x & 7, blockIdx.x >> 3, lds, &f);
 }
 
 // Two independent layers in one grid (same tile shape, no split-K): the first tiles_a workgroups
@@ -755,9 +865,217 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_pair_kernel(const ConvKArgs 
     __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * (BKB / 4 + 4)];
     // two copies of the tile code, each reading its own kernel arguments straight from SGPRs
     if ((int)blockIdx.x < tiles_a)
-        conv_tile<E, BM, BN, BKB / (int)sizeof(E), KW>(a, blockIdx.x, lds);
+        conv_tile<E, BM, BN, BKB / (int)sizeof(E), KW>(a, blockIdx.x & 7, blockIdx.x >> 3, lds);
     else
-        conv_tile<E, BM, BN, BKB / (int)sizeof(E), KW>(b, blockIdx.x - tiles_a, lds);
+        conv_tile<E, BM, BN, BKB / (int)sizeof(E), KW>(b, (blockIdx.x - tiles_a) & 7, (blockIdx.x - tiles_a) >> 3, lds);
+}
+
+// ----------------------------------------------------------------------------- layer chains
+// A run of dependent layers in ONE launch.  Rows of different images never interact, so the images
+// are cut into 8 shares and every XCD walks the whole run for its share: producer and consumer of
+// every intermediate sit on the same XCD, the hand-off between two layers is a store drain, one L2
+// atomic and an L1-bypassing load (about 2 us, measured by tools/micro/xcd_barrier.hip; a hand-off
+// that crosses XCDs needs an L2 write-back and costs twenty times that), and the launch, argument
+// fetch and weight-load latency of every layer but the first disappear behind the previous layer.
+//
+// The grid is resident as a whole (the host sizes it from the occupancy query).  Workgroups find out
+// where they run from the hardware's XCC_ID, register, and wait until everybody has: after that each
+// knows how many workgroups every XCD got.  Populated XCDs take the shares in turn (XCD of rank r
+// among P takes shares r, r + P, ...: with the usual even deal, one each), the members of an XCD split
+// each step's tiles statically (member j takes tiles j, j + members, ...), publish the step in a word of their own
+// after their last tile and wait for the previous step's counter ahead of their first.  Nothing
+// depends on how the dispatcher deals workgroups to XCDs except the speed.
+constexpr int CHAIN_MAX_STEPS = 192;  // ResNet152 behind its first stage: 47 blocks x 3
+constexpr int CHAIN_MAX_SHARES = 16;  // 8 XCDs x up to two teams
+constexpr int CHAIN_MAX_MEMBERS = 1024;  // workgroups of one launch (all of them may land on one XCD)
+
+//
+// An address must not be written by two XCDs in one launch (two L2s would each hold a dirty copy and
+// the order of their write-backs decides what memory ends up with), and nothing a slower XCD still
+// has to read may be overwritten by a faster one.  So every buffer a chain writes is cut into 8 fixed
+// slices, one per share, whatever the layer: share s keeps its rows of every intermediate at
+// slice s (`gap` = slice size - the layer's bytes per share, added to the base once per share), the
+// chain's input is only read, and its final output has a buffer of its own.
+struct ChainStep {
+    ConvKArgs a[2];  // one layer, or two that read the same input; in / res / out hold byte offsets into the workspace
+    int tiles[2];    // tiles per share of each (0: absent)
+    int shape[2];    // tile shape code of each (64, 32, TILE_32x32)
+    unsigned gap_in[2], gap_res[2], gap_out[2];  // bytes per share by which the buffer's slices exceed the layer's rows (0: standard layout)
+};
+
+struct ChainCtl {  // zeroed ahead of every launch
+    unsigned arrived, status, pad0[30];
+    unsigned members[8][32];                        // per XCD (one 128-byte line each): workgroups that were [0] the first, [1] the second, [2] a further one on their CU
+    unsigned cu_count[8][256];                      // per XCD and CU (HW_ID bits 8-15): workgroups registered
+    unsigned cu_first[8][256];                      // 1 + the ticket of the CU's first workgroup
+    unsigned flags[CHAIN_MAX_SHARES][CHAIN_MAX_MEMBERS];  // per share and member: steps finished (1 + the last step's index)
+};
+
+__device__ __forceinline__ ConvKArgs chain_load_args(const ChainStep *steps, int s, int which, char *ws, int share) {
+    // copied word by word through the constant address space: scalar loads into SGPRs
+    typedef const __attribute__((address_space(4))) unsigned *const_u32_ptr;
+    static_assert(sizeof(ConvKArgs) % 4 == 0, "ConvKArgs is copied in 32-bit words");
+    constexpr int WORDS = (int)sizeof(ConvKArgs) / 4;
+    union {
+        ConvKArgs a;
+        unsigned w[WORDS];
+    } u;
+    const const_u32_ptr src = (const_u32_ptr)(uintptr_t)&steps[s].a[which];
+#pragma unroll
+    for (int i = 0; i < WORDS; ++i) u.w[i] = src[i];
+    ConvKArgs a = u.a;
+    typedef const __attribute__((address_space(4))) unsigned *const_gap_ptr;
+    const const_gap_ptr gaps = (const_gap_ptr)(uintptr_t)steps[s].gap_in;  // gap_in[2], gap_res[2], gap_out[2]
+    a.in = ws + (size_t)a.in + (size_t)share * gaps[which];
+    a.out = ws + (size_t)a.out + (size_t)share * gaps[4 + which];
+    a.res = a.res == (const void *)~(uintptr_t)0 ? nullptr : (const void *)(ws + (size_t)a.res + (size_t)share * gaps[2 + which]);
+    return a;
+}
+
+#ifdef GDPSO_STAMPS
+// Diagnostic build only (tools/chain_probe.py): per workgroup and step, s_memrealtime (100 MHz) when
+// the step was entered, when its wait ended, when its tiles were done and when it was signalled.
+__device__ unsigned long long *g_chain_stamps = nullptr;
+#endif
+
+__global__ __launch_bounds__(256, 2) void conv_chain_kernel(const ChainStep *steps, int nsteps, char *ws, ChainCtl *ctl,
+                                                             unsigned drop_xcc_mask, int nteams, unsigned stagger_ticks) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * 64 * 132];  // the largest of the three tile shapes
+    __shared__ int s_reg[12];
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg(63508) & 7u;  // HW_REG_XCC_ID
+        const bool dropped = (drop_xcc_mask >> xcc) & 1u;            // test aid: behave as if this XCD had got no workgroup
+        // Arrival order on the CU (0: first, 1: second, 2: any further), then a ticket among the XCD's
+        // workgroups of that order; the first of a CU leaves its ticket for the second to find.  Every
+        // returned value is consumed before the arrival is counted, so whoever sees the full count sees these.
+        const unsigned cu = (__builtin_amdgcn_s_getreg(63492) >> 8) & 0xffu;  // HW_REG_HW_ID: CU, shader array, shader engine
+        unsigned k = 0, j = 0;
+        if (!dropped) {
+            k = min(2u, __hip_atomic_fetch_add(&ctl->cu_count[xcc][cu], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            j = __hip_atomic_fetch_add(&ctl->members[xcc][k], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (k == 0) __hip_atomic_store(&ctl->cu_first[xcc][cu], j + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(j) : "memory");
+        __hip_atomic_fetch_add(&ctl->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        bool ok = true;
+        while (__hip_atomic_load(&ctl->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+            ++spins;
+            if ((spins & 255u) == 0 &&
+                (spins > CHAIN_SPIN_LIMIT || __hip_atomic_load(&ctl->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                chain_abort(&ctl->status, 2u);
+                ok = false;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        int populated = 0, rank = 0;
+        unsigned m0 = 0, m1 = 0, m2 = 0;
+        for (unsigned x = 0; x < 8; ++x) {
+            const unsigned f = __hip_atomic_load(&ctl->members[x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            populated += f != 0;
+            rank += (f != 0 && x < xcc);
+            if (x == xcc) {
+                m0 = f;
+                m1 = __hip_atomic_load(&ctl->members[x][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                m2 = __hip_atomic_load(&ctl->members[x][2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        // The usual deal puts exactly two workgroups on every CU.  Then the second of a CU is numbered
+        // from the far end of where its first stands: with one team per XCD (members 0 .. 2 m0 - 1) a CU
+        // holds members i and 2 m0 - 1 - i, so a step with up to m0 tiles runs one tile per CU and a step whose
+        // tiles are sorted heaviest first pairs heavy with light; with two teams per XCD (the firsts and the
+        // seconds, each 0 .. m0 - 1) a CU holds member i of one team and m0 - 1 - i of the other.
+        // Any other deal: one team of all the XCD's workgroups in ticket order.
+        const bool paired = m1 == m0 && m2 == 0;
+        int team = 0, local_teams = 1, member, members;
+        if (paired) {
+            const unsigned j0 = k == 0 ? j : __hip_atomic_load(&ctl->cu_first[xcc][cu], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1u;
+            if (nteams == 2) {
+                team = (int)k;
+                local_teams = 2;
+                member = (int)(k == 0 ? j0 : m0 - 1u - j0);
+                members = (int)m0;
+            } else {
+                member = (int)(k == 0 ? j0 : 2u * m0 - 1u - j0);
+                members = (int)(2u * m0);
+            }
+        } else {
+            member = (int)(k == 0 ? j : k == 1 ? m0 + j : m0 + m1 + j);
+            members = (int)(m0 + m1 + m2);
+        }
+        s_reg[0] = ok && !dropped ? 1 : 0;
+        s_reg[1] = member;
+        s_reg[2] = members;
+        s_reg[3] = rank;
+        s_reg[4] = populated;
+        s_reg[5] = team;
+        s_reg[6] = local_teams;
+        if (team == 1 && stagger_ticks) {  // the second team starts late, so that the two teams' hand-offs do not coincide
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (__builtin_amdgcn_s_memrealtime() - t0 < stagger_ticks) __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
+    if (!s_reg[0]) return;
+    const int member = s_reg[1], members = s_reg[2], rank = s_reg[3], populated = s_reg[4], team = s_reg[5], local_teams = s_reg[6];
+    // populated XCDs take the 8 groups of shares in turn, an XCD's teams the shares of a group
+    for (int sidx = rank * nteams + team; sidx < 8 * nteams;) {
+        const int share = sidx;
+        int prev_tiles = 0;
+        for (int s = 0; s < nsteps; ++s) {
+            typedef const __attribute__((address_space(4))) int *const_int_ptr;
+            const const_int_ptr meta = (const_int_ptr)(uintptr_t)steps[s].tiles;  // tiles[2], shape[2]
+            const int ta = meta[0], ntile = ta + meta[1];
+            bool first = true;
+#ifdef GDPSO_STAMPS
+            unsigned long long *const stamps = g_chain_stamps ? g_chain_stamps + ((size_t)blockIdx.x * CHAIN_MAX_STEPS + s) * 4 : nullptr;
+            if (stamps && tid == 0 && member < ntile) stamps[0] = __builtin_amdgcn_s_memrealtime();
+            if (stamps && tid == 0 && s == 0)  // last step slot: share + 1, member
+                g_chain_stamps[((size_t)blockIdx.x * CHAIN_MAX_STEPS + CHAIN_MAX_STEPS - 1) * 4] = (unsigned long long)(share + 1) | ((unsigned long long)member << 8);
+#endif
+            for (int t = member; t < ntile; t += members) {
+                const int which = t >= ta;
+                const int slot = t - (which ? ta : 0);
+                const int shape = meta[2 + which];
+                ChainWait w;
+                if (first && s > 0) {
+                    w.flags = ctl->flags[share];
+                    w.target = (unsigned)s;  // step s - 1 finished
+                    w.count = min(members, prev_tiles);
+                    w.status = &ctl->status;
+#ifdef GDPSO_STAMPS
+                    w.stamp = stamps ? stamps + 1 : nullptr;
+#endif
+                }
+                if (!first) __syncthreads();  // the previous tile's store pass has left the LDS
+                const ConvKArgs a = chain_load_args(steps, s, which, ws, share);
+                if (shape == 64)
+                    conv_tile<float, 64, 64, 32, 1, false, true>(a, share, slot, lds, nullptr, w);
+                else if (shape == 32)
+                    conv_tile<float, 32, 64, 64, 2, false, true>(a, share, slot, lds, nullptr, w);
+                else
+                    conv_tile<float, 32, 32, 128, 4, false, true>(a, share, slot, lds, nullptr, w);
+                first = false;
+            }
+            if (!first) {
+#ifdef GDPSO_STAMPS
+                if (stamps && tid == 0) stamps[2] = __builtin_amdgcn_s_memrealtime();
+#endif
+                // the step's results are in the L2 once the stores have been acknowledged
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store(&ctl->flags[share][member], (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef GDPSO_STAMPS
+                if (stamps && tid == 0) stamps[3] = __builtin_amdgcn_s_memrealtime();
+#endif
+            }
+            prev_tiles = ntile;
+        }
+        const int u = sidx % nteams;
+        sidx += u + local_teams < nteams ? local_teams : populated * nteams - u + team;
+    }
 }
 
 // Sums the split-K slabs and applies the epilogue.  Four channels per thread.
@@ -890,7 +1208,7 @@ int conv_splitk_prepare(hipStream_t stream, float *splitk_ws) {
 
 // Fills the kernel arguments of one layer; returns its number of workgroups per split through *tiles.
 static int conv_args(const ConvLayer &L, int n_images, const void *in, const void *res, void *out, float *splitk_ws,
-                     ConvKArgs &a, long *grid_x, bool *fused_reduce) {
+                     ConvKArgs &a, long *grid_x, bool *fused_reduce, int nshare = 8) {
     if (!dtype_ok(L.dtype)) return fail(GDPSO_ERR_ARG, "conv: unknown element type");
     a.in = in; a.wt = L.wt; a.scale = L.scale; a.shift = L.shift; a.res = res; a.out = out;
     const long tiles_m = m_tiles(L, n_images, L.tile);
@@ -904,12 +1222,12 @@ static int conv_args(const ConvLayer &L, int n_images, const void *in, const voi
             continue;
         }
         const long tiles = (long)ceil_div((long)n_images * L.phase[p].hm * L.phase[p].wm, tile_bm(L.tile)) * (L.cout / tile_bn(L.tile));
-        const long eighth = ceil_div(tiles, 8);
+        const long eighth = ceil_div(tiles, nshare);  // a share's part (an XCD's eighth outside chains)
         per_xcd += eighth;
-        a.phase_word[p] = (unsigned)per_xcd | ((unsigned)(8 * eighth - tiles) << 24);
+        a.phase_word[p] = (unsigned)per_xcd | ((unsigned)(nshare * eighth - tiles) << 24);
     }
     if (per_xcd >= 0xffffff) return fail(GDPSO_ERR_ARG, "conv: too many tiles");
-    *grid_x = 8 * per_xcd;
+    *grid_x = nshare * per_xcd;
     a.per_xcd = (int)per_xcd;
     a.snake = (g_snake && L.nphase > 1 && per_xcd > g_cus_per_xcd && per_xcd <= 2 * g_cus_per_xcd) ? g_cus_per_xcd : 0;
     // in-kernel (last-arriver) reduction up to GDPSO_SPLITK_FUSED_MAX splits (default: off); one counter per workgroup index
@@ -1093,7 +1411,190 @@ int launch_conv_pair(const ConvLayer &La, const ConvLayer &Lb, hipStream_t strea
     return GDPSO_OK;
 }
 
+// ---- chains (see conv_chain_kernel)
+static bool g_chain_enabled = [] {
+    const char *e = getenv("GDPSO_CONV_CHAIN");
+    return e ? e[0] != '0' : true;
+}();
+static unsigned g_chain_drop_mask = 0;  // test aid, see gdpso_chain_debug
+// Teams per XCD (GDPSO_CHAIN_TEAMS=1|2) and, with two, how long the second starts after the first
+// (GDPSO_CHAIN_STAGGER_US), so that one team computes while the other hands over.
+static int g_chain_teams = [] {
+    const char *e = getenv("GDPSO_CHAIN_TEAMS");
+    return e && atoi(e) == 2 ? 2 : 1;
+}();
+static unsigned g_chain_stagger = [] {
+    const char *e = getenv("GDPSO_CHAIN_STAGGER_US");
+    return (unsigned)(100.0 * (e ? atof(e) : 6.0));  // s_memrealtime ticks (100 MHz)
+}();
+int chain_teams() { return g_chain_teams; }
+
+struct ConvChain {
+    std::vector<ChainStep> steps;
+    std::deque<ConvLayer> layers;  // the chain's own copies (its tile choice), in step order
+    std::vector<char> layer_has_res;
+    int n_images = 0;
+    int nteams = 1;   // teams per XCD: 8 * nteams shares
+    int nshare() const { return 8 * nteams; }
+    void *dev_steps = nullptr;
+    size_t ctl_off = 0;
+    int grid = 0;
+    ~ConvChain() {
+        if (dev_steps) (void)hipFree(dev_steps);
+    }
+};
+
+bool chain_enabled() { return g_chain_enabled; }
+size_t chain_ctl_bytes() { return sizeof(ChainCtl); }
+ConvChain *chain_new(int n_images, int nteams) {
+    auto c = new ConvChain();
+    c->n_images = n_images;
+    c->nteams = nteams == 2 ? 2 : 1;
+    return c;
+}
+void chain_free(ConvChain *c) { delete c; }
+int chain_steps(const ConvChain *c) { return c ? (int)c->steps.size() : 0; }
+
+// The tile shape a layer runs with as a step of a chain over `nshare` shares of the images (0: it cannot
+// be a step): fp32, unsplit, one of the three small shapes, and every phase's rows of one share fill
+// whole tiles.  The planner's shape if that holds for it, else the next smaller one.
+int chain_tile(const ConvLayer &L, int n_images, int nshare) {
+    if (L.dtype != DT_F32 || L.splits != 1 || n_images % nshare != 0) return 0;
+    const int order[3] = {64, 32, TILE_32x32};
+    for (int t : order) {
+        if (tile_bm(t) > tile_bm(L.tile) || (tile_bm(t) == tile_bm(L.tile) && tile_bn(t) > tile_bn(L.tile))) continue;  // not larger than planned
+        if (t == 32 && L.cin % 64 != 0) continue;
+        if (t == TILE_32x32 && L.cin % 128 != 0) continue;
+        if (L.cout % tile_bn(t) != 0) continue;
+        bool ok = true;
+        for (int p = 0; p < L.nphase && ok; ++p)
+            ok = ((long)(n_images / nshare) * L.phase[p].hm * L.phase[p].wm) % tile_bm(t) == 0;
+        if (ok) return t;
+    }
+    return 0;
+}
+bool chain_layer_ok(const ConvLayer &L, int n_images, int nteams) { return chain_tile(L, n_images, 8 * (nteams == 2 ? 2 : 1)) != 0; }
+
+// slice size - bytes of one share's rows (pixels per image x channels); 0 for a buffer in standard layout
+static int chain_gap(const ConvChain &c, const ChainBuf &b, long pixels, int channels, unsigned *gap) {
+    *gap = 0;
+    if (b.bytes == 0) return GDPSO_OK;
+    const size_t slice = b.bytes / c.nshare() / 16 * 16;
+    const size_t share_bytes = (size_t)(c.n_images / c.nshare()) * pixels * channels * sizeof(float);
+    if (slice < share_bytes || slice - share_bytes > 0xffffffffu) return fail(GDPSO_ERR_ARG, "chain: buffer too small for a layer's share");
+    *gap = (unsigned)(slice - share_bytes);
+    return GDPSO_OK;
+}
+
+static int chain_fill(const ConvChain &c, const ConvLayer &L, const ChainBuf &in, const ChainBuf *res, const ChainBuf &out,
+                      ChainStep &st, int w) {
+    long grid_x = 0;
+    bool fr = false;
+    ConvKArgs &a = st.a[w];
+    int rc = conv_args(L, c.n_images, (const void *)in.offset, res ? (const void *)(uintptr_t)1 : nullptr, (void *)out.offset, nullptr, a,
+                       &grid_x, &fr, c.nshare());
+    if (rc) return rc;
+    a.res = res ? (const void *)res->offset : (const void *)~(uintptr_t)0;
+    a.snake = 0;
+    st.tiles[w] = (int)(grid_x / c.nshare());
+    st.shape[w] = L.tile;
+    if ((rc = chain_gap(c, in, (long)L.hin * L.win, L.cin, &st.gap_in[w]))) return rc;
+    if ((rc = chain_gap(c, out, (long)L.hout * L.wout, L.cout, &st.gap_out[w]))) return rc;
+    if (res && (rc = chain_gap(c, *res, (long)L.hout * L.wout, L.cout, &st.gap_res[w]))) return rc;
+    return GDPSO_OK;
+}
+
+// Appends a step: layer La (input at byte offset `in` of the workspace, optional residual, output), and
+// optionally Lb reading the same input (no residual).
+int chain_add(ConvChain *c, const ConvLayer *La, const ChainBuf &in, const ChainBuf *res, const ChainBuf &out_a, const ConvLayer *Lb,
+              const ChainBuf *out_b) {
+    if ((int)c->steps.size() >= CHAIN_MAX_STEPS) return fail(GDPSO_ERR_ARG, "chain: too many steps");
+    const int ta = chain_tile(*La, c->n_images, c->nshare()), tb = Lb ? chain_tile(*Lb, c->n_images, c->nshare()) : 1;
+    if (!ta || !tb) return fail(GDPSO_ERR_ARG, "chain: layer cannot be chained at this batch size");
+    ChainStep st;
+    std::memset(&st, 0, sizeof(st));
+    c->layers.push_back(*La);
+    c->layers.back().tile = ta;
+    int rc = chain_fill(*c, c->layers.back(), in, res, out_a, st, 0);
+    if (rc) return rc;
+    c->layer_has_res.push_back(res != nullptr);
+    if (Lb) {
+        if (!out_b) return fail(GDPSO_ERR_ARG, "chain: second layer without an output");
+        c->layers.push_back(*Lb);
+        c->layers.back().tile = tb;
+        if ((rc = chain_fill(*c, c->layers.back(), in, nullptr, *out_b, st, 1))) return rc;
+        c->layer_has_res.push_back(0);
+    }
+    c->steps.push_back(st);
+    return GDPSO_OK;
+}
+
+// Uploads the step table and sizes the grid: every workgroup must be resident at once.
+int chain_finish(ConvChain *c, size_t ctl_off) {
+    if (c->steps.empty()) return fail(GDPSO_ERR_ARG, "chain: no steps");
+    int dev = 0, cus = 0, occ = 0;
+    GDPSO_HIP(hipGetDevice(&dev));
+    GDPSO_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    GDPSO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_chain_kernel, 256, 0));
+    if (occ < 1) return fail(GDPSO_ERR_HIP, "chain: the kernel does not fit a compute unit");
+    c->grid = cus * std::min(occ, 2);
+    if (c->grid > CHAIN_MAX_MEMBERS) return fail(GDPSO_ERR_ARG, "chain: more workgroups than the control block holds");
+    c->ctl_off = ctl_off;
+    GDPSO_HIP(hipMalloc(&c->dev_steps, c->steps.size() * sizeof(ChainStep)));
+    GDPSO_HIP(hipMemcpy(c->dev_steps, c->steps.data(), c->steps.size() * sizeof(ChainStep), hipMemcpyHostToDevice));
+    return GDPSO_OK;
+}
+
+int launch_chain(const ConvChain *c, hipStream_t stream, void *workspace) {
+    char *ws = (char *)workspace;
+    ChainCtl *ctl = (ChainCtl *)(ws + c->ctl_off);
+    GDPSO_HIP(hipMemsetAsync(ctl, 0, sizeof(ChainCtl), stream));
+    const bool timed = g_timing.on && g_timing.used + 2 <= g_timing.events.size();
+    const dim3 grid((unsigned)c->grid);
+    if (timed) {
+        hipExtLaunchKernelGGL(conv_chain_kernel, grid, dim3(256), 0, stream, g_timing.events[g_timing.used],
+                              g_timing.events[g_timing.used + 1], 0, (const ChainStep *)c->dev_steps, (int)c->steps.size(), ws, ctl,
+                              g_chain_drop_mask, c->nteams, g_chain_stagger);
+        g_timing.used += 2;
+        size_t li = 0;
+        for (const ChainStep &st : c->steps)
+            for (int w = 0; w < 2; ++w)
+                if (st.tiles[w]) {
+                    conv_account(c->layers[li], c->n_images, st.a[w], c->layer_has_res[li] != 0);
+                    ++li;
+                }
+    } else {
+        hipLaunchKernelGGL(conv_chain_kernel, grid, dim3(256), 0, stream, (const ChainStep *)c->dev_steps, (int)c->steps.size(), ws, ctl,
+                           g_chain_drop_mask, c->nteams, g_chain_stagger);
+    }
+    GDPSO_HIP(hipGetLastError());
+    return GDPSO_OK;
+}
+
 }  // namespace gdpso
+
+// Development / test switches of the chained launches: `enabled` 0 runs every layer as a launch of its
+// own (plans made afterwards); `drop_xcc_mask` makes the workgroups on those XCDs stand aside, so that
+// the other XCDs take their shares as well (the path for an uneven deal of workgroups to XCDs);
+// `teams` (0: unchanged) sets the teams per XCD of plans made afterwards.
+extern "C" int gdpso_chain_debug(int enabled, unsigned drop_xcc_mask, int teams) {
+    using namespace gdpso;
+    GDPSO_REQUIRE((drop_xcc_mask & 0xffu) != 0xffu, "chain_debug: at least one XCD must keep its workgroups");
+    GDPSO_REQUIRE(teams >= 0 && teams <= 2, "chain_debug: teams must be 0 (keep), 1 or 2");
+    g_chain_enabled = enabled != 0;
+    g_chain_drop_mask = drop_xcc_mask & 0xffu;
+    if (teams) g_chain_teams = teams;
+    return GDPSO_OK;
+}
+
+// Chains that ran out of patience waiting for a step since the library was loaded (0 on a healthy
+// device).  Synchronises the device.
+extern "C" int gdpso_chain_aborts(unsigned *count) {
+    using namespace gdpso;
+    GDPSO_REQUIRE(count, "chain_aborts: null pointer");
+    GDPSO_HIP(hipMemcpyFromSymbol(count, HIP_SYMBOL(g_chain_aborts), sizeof(unsigned)));
+    return GDPSO_OK;
+}
 
 extern "C" int gdpso_conv_timing_begin(int max_launches) {
     using namespace gdpso;
@@ -1130,6 +1631,11 @@ extern "C" int gdpso_conv_timing_end(double *total_ms, int *launches, double *fl
 #ifdef GDPSO_STAMPS
 extern "C" int gdpso_conv_stamps_set(void *device_buffer) {
     GDPSO_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gdpso::g_stamps), &device_buffer, sizeof(void *)));
+    return GDPSO_OK;
+}
+// [workgroups][CHAIN_MAX_STEPS = 192][4] 64-bit stamps
+extern "C" int gdpso_chain_stamps_set(void *device_buffer) {
+    GDPSO_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gdpso::g_chain_stamps), &device_buffer, sizeof(void *)));
     return GDPSO_OK;
 }
 

@@ -818,6 +818,7 @@ struct gdpso_assessor {
     int n_class, side, ho, hp, stem_band, stem_ps;
     const float *stem_w, *stem_scale, *stem_shift;
     std::vector<Bottleneck> blocks;
+    int chain_first = 0;  // first block behind the first stage
     const float *fc_w, *fc_b;
     int feat_c, feat_hw;
     double flops;
@@ -826,9 +827,17 @@ struct gdpso_assessor {
 };
 
 struct AssLayout {
-    size_t x, y, t1, t2, sc, splitk, total;
+    size_t x, y, t1, t2, sc, splitk, chain_ctl, chain_z, chain_out, total;
     std::vector<Bottleneck> blocks;
     ConvLayer alex_conv[3], alex_fc[2];  // AlexNet: the handle's layers with this batch size's launch plan
+    // blocks [chain_first, end) as one persistent launch, when every layer of theirs can be chained at
+    // this batch size (null otherwise: a launch per layer)
+    ConvChain *chain = nullptr;
+    int chain_first = 0;
+    AssLayout() = default;
+    AssLayout(const AssLayout &) = delete;
+    AssLayout &operator=(const AssLayout &) = delete;
+    ~AssLayout() { chain_free(chain); }
 };
 namespace {
 std::shared_ptr<const AssLayout> ass_layout(const gdpso_assessor *a, int n) {
@@ -877,6 +886,58 @@ std::shared_ptr<const AssLayout> ass_layout(const gdpso_assessor *a, int n) {
     L.t2 = off; off += align_up(t2 * es);
     L.sc = off; off += align_up(sc * es);
     L.splitk = off; off += align_up(sk);
+    L.chain_ctl = L.chain_z = L.chain_out = 0;
+    // Every stage behind the first in one launch (the first stage's layers are long enough for their
+    // launches not to matter, and two of its three layers per block already share one).  The chain reads
+    // the first stage's output where it lies, keeps its intermediates in per-share slices of y-or-x / z /
+    // t1 / t2 / sc and writes the last block's output to a buffer of its own.
+    L.chain_first = a->chain_first;
+    if (a->kind == 0 && chain_enabled() && L.chain_first > 0 && L.chain_first < (int)L.blocks.size()) {
+        size_t zmax = 0;
+        for (size_t i = L.chain_first; i < L.blocks.size(); ++i) zmax = std::max(zmax, out_elems(L.blocks[i].c3));
+        int nteams = 0;
+        for (int t = chain_teams(); t >= 1 && !nteams; --t) {  // two teams per XCD need whole tiles in a sixteenth of the images
+            bool ok = true;
+            for (size_t i = L.chain_first; i < L.blocks.size() && ok; ++i) {
+                const Bottleneck &b = L.blocks[i];
+                ok = chain_layer_ok(b.c1, n, t) && chain_layer_ok(b.c2, n, t) && chain_layer_ok(b.c3, n, t) && (!b.has_ds || chain_layer_ok(b.ds, n, t));
+            }
+            if (ok) nteams = t;
+        }
+        if (nteams) {
+            const size_t xy_bytes = align_up(xy * es), z_bytes = align_up(zmax * es);
+            L.chain_ctl = off; off += align_up(chain_ctl_bytes());
+            L.chain_z = off; off += z_bytes;
+            L.chain_out = off; off += align_up(out_elems(L.blocks.back().c3) * es);
+            ConvChain *c = chain_new(n, nteams);
+            const bool even = L.chain_first % 2 == 0;  // the first stage's output is in x after an even number of blocks
+            const ChainBuf input{even ? L.x : L.y, 0}, ping{even ? L.y : L.x, xy_bytes}, pong{L.chain_z, z_bytes};
+            const ChainBuf bt1{L.t1, align_up(t1 * es)}, bt2{L.t2, align_up(t2 * es)}, bsc{L.sc, align_up(sc * es)};
+            const ChainBuf fin{L.chain_out, 0};
+            ChainBuf cur = input;
+            int rc = GDPSO_OK;
+            for (size_t i = L.chain_first; i < L.blocks.size() && !rc; ++i) {
+                const Bottleneck &b = L.blocks[i];
+                const bool last = i + 1 == L.blocks.size();
+                const ChainBuf next = last ? fin : ((i - L.chain_first) % 2 == 0 ? ping : pong);
+                ChainBuf res = cur;
+                if (b.has_ds) {
+                    rc = chain_add(c, &b.ds, cur, nullptr, bsc, &b.c1, &bt1);
+                    res = bsc;
+                } else {
+                    rc = chain_add(c, &b.c1, cur, nullptr, bt1);
+                }
+                if (!rc) rc = chain_add(c, &b.c2, bt1, nullptr, bt2);
+                if (!rc) rc = chain_add(c, &b.c3, bt2, &res, next);
+                cur = next;
+            }
+            if (!rc) rc = chain_finish(c, L.chain_ctl);
+            if (rc)
+                chain_free(c);  // the per-layer launches remain
+            else
+                L.chain = c;
+        }
+    }
     L.total = off;
     if (a->plans.size() >= MAX_CACHED_PLANS) a->plans.clear();
     a->plans[n] = Lp;
@@ -962,6 +1023,7 @@ extern "C" int gdpso_assessor_create_resnet_typed(gdpso_assessor **out, const in
     }
     a->feat_c = cin;
     a->feat_hw = h * h;
+    a->chain_first = depths[0];
     {
         std::vector<float> w(t[ti], t[ti] + (size_t)n_class * cin), b(t[ti + 1], t[ti + 1] + n_class);
         if ((rc = a->arena.upload(w, &a->fc_w)) || (rc = a->arena.upload(b, &a->fc_b))) { delete a; return rc; }
@@ -1125,7 +1187,13 @@ static int assessor_forward_impl(const gdpso_assessor *a, void *stream_, int n, 
     }
     int rc;
     if ((rc = conv_splitk_prepare(stream, sk))) return rc;
-    for (const Bottleneck &b : L.blocks) {
+    for (size_t bi = 0; bi < L.blocks.size(); ++bi) {
+        const Bottleneck &b = L.blocks[bi];
+        if (L.chain && (int)bi >= L.chain_first) {
+            if ((int)bi == L.chain_first && (rc = launch_chain(L.chain, stream, workspace))) return rc;
+            x = ws + L.chain_out;  // (the remaining blocks are all part of the chain)
+            continue;
+        }
         const void *res = x;
         if (b.has_ds) {  // identity_downsample and conv1 read the same input: one launch when their shapes allow
             if ((rc = launch_conv_pair(b.ds, b.c1, stream, n, x, sc, t1, sk))) return rc;

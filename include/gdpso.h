@@ -346,6 +346,20 @@ int gdpso_conv_plan_describe(int n_images, int hin, int cin, int cout, int ksize
  * with the exact quotient.  0 <= n < 2^31, d >= 1. */
 unsigned gdpso_fast_div_check(unsigned n, unsigned d);
 
+/* No counterpart in the reference: switches of the chained launch (every convolution of the ResNet
+ * stages behind the first in ONE persistent launch whose workgroups hand intermediates to each other
+ * inside an XCD's L2).  enabled = 0: launch plans made from now on run one launch per layer (A/B runs
+ * and tests); drop_xcc_mask: workgroups on these XCDs (bits 0-7, not all) stand aside, which exercises the
+ * path for an uneven deal of workgroups to XCDs (a test aid; results do not change); teams (0: keep,
+ * 1, 2): teams of workgroups per XCD in plans made from now on (two teams each own a sixteenth of the
+ * images and walk the layers independently; measured slower than one on MI355X, kept as an A/B switch). */
+int gdpso_chain_debug(int enabled, unsigned drop_xcc_mask, int teams);
+
+/* No counterpart in the reference: number of chained launches since the library was loaded that gave up
+ * waiting for a step (0 on a healthy device; such a launch ends with wrong results instead of hanging).
+ * Synchronises the device. */
+int gdpso_chain_aborts(unsigned *count);
+
 /* No counterpart in the reference: times one ksize x ksize convolution layer in isolation
  * on random data (allocates and frees its own buffers; a development / tuning aid).
  * tile (0 = planner's choice; 128 = 128x128, 64 = 64x64, 32 = 32x64 with the K-tile split over two wave

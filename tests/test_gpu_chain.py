@@ -1,0 +1,108 @@
+"""The chained launch (every convolution of the ResNet stages behind the first in one persistent
+launch, intermediates handed over inside an XCD's L2) against the per-layer launches of the same
+plan -- bit for bit, the tile code and the summation order are the same -- and against the oracle;
+with an even deal of workgroups to XCDs and with XCDs standing aside (the uneven-deal path)."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def eng():
+    return importlib.import_module("gan-discovery-pso_amd.engine")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return importlib.import_module("gan-discovery-pso_amd._lib")
+
+
+def _aborts(lib):
+    c = C.c_uint(0)
+    lib.check(lib.lib().gdpso_chain_aborts(C.byref(c)))
+    return c.value
+
+
+def _logits(eng, lib, synth, model, n, side, chained, drop=0, seed=5, teams=1):
+    """Logits of `n` seeded images through a fresh assessor whose plans are made with the switch set."""
+    dev = torch.device("cuda:0")
+    lib.check(lib.lib().gdpso_chain_debug(int(chained), drop, teams))
+    try:
+        ass = eng.PackedAssessor(synth.resnet_state(model, 1, 8, seed=12), dev, img_side=side)
+        gen = eng.PackedGenerator(synth.generator_state(10, 1, 64, seed=11, first_kernel=side // 4), dev)
+        ev = eng.Evaluator(gen, ass)
+        x = torch.from_numpy(np.random.RandomState(seed).random_sample((n, side, side)).astype(np.float32)).cuda()
+        out = []
+        for _ in range(3):  # the same buffers again: stale cache lines would show on the second pass
+            _, logits = ev.assess(x, eng.FitnessSpec(class_index=0), want_logits=True)
+            out.append(logits.cpu().numpy().copy())
+        torch.cuda.synchronize()
+    finally:
+        lib.check(lib.lib().gdpso_chain_debug(1, 0, 1))
+    for o in out[1:]:
+        np.testing.assert_array_equal(o, out[0])
+    return out[0], x
+
+
+@pytest.mark.parametrize("model,n,side", [("ResNet50", 512, 28), ("ResNet50", 256, 28), ("ResNet50", 1024, 28),
+                                           ("ResNet101", 512, 28), ("ResNet50", 512, 64)])
+def test_chain_matches_per_layer_launches(eng, lib, synth, model, n, side):
+    before = _aborts(lib)
+    plain, _ = _logits(eng, lib, synth, model, n, side, chained=False)
+    chained, _ = _logits(eng, lib, synth, model, n, side, chained=True)
+    np.testing.assert_array_equal(chained, plain)
+    assert _aborts(lib) == before
+
+
+@pytest.mark.parametrize("drop", [0xF0, 0x0F, 0xFE, 0x24])
+def test_chain_with_xcds_standing_aside(eng, lib, synth, drop):
+    before = _aborts(lib)
+    plain, _ = _logits(eng, lib, synth, "ResNet50", 512, 28, chained=False)
+    chained, _ = _logits(eng, lib, synth, "ResNet50", 512, 28, chained=True, drop=drop)
+    np.testing.assert_array_equal(chained, plain)
+    assert _aborts(lib) == before
+
+
+@pytest.mark.parametrize("drop", [0, 0xF0, 0x7F])
+def test_two_teams_per_xcd(eng, lib, synth, drop):
+    """Two teams per XCD (sixteen shares): some layers then run with smaller tiles, whose K parts are
+    added in another order, so the comparison is to fp32 rounding, not bit for bit."""
+    before = _aborts(lib)
+    plain, _ = _logits(eng, lib, synth, "ResNet50", 512, 28, chained=False)
+    chained, _ = _logits(eng, lib, synth, "ResNet50", 512, 28, chained=True, drop=drop, teams=2)
+    np.testing.assert_allclose(chained, plain, rtol=1e-4, atol=2e-4)
+    assert _aborts(lib) == before
+
+
+def test_chain_against_oracle(eng, lib, synth, oracle):
+    n = 512
+    got, x = _logits(eng, lib, synth, "ResNet50", n, 28, chained=True, seed=9)
+    csd = synth.to_torch(synth.resnet_state("ResNet50", 1, 8, seed=12))
+    sel = np.concatenate([[0, 63, 64, n - 1], np.random.RandomState(1).choice(n, 12, replace=False)])
+    with torch.no_grad():
+        want = oracle.resnet_forward(csd, torch.from_numpy(x.cpu().numpy()[sel][:, None])).numpy()
+    np.testing.assert_allclose(got[sel], np.asarray(want), rtol=1e-4, atol=2e-4)
+
+
+def test_swarm_run_is_the_same_chained(eng, lib, synth):
+    """A whole 512-particle swarm run (Philox draws on the device) ends in the same state either way."""
+    dev = torch.device("cuda:0")
+    res = []
+    for chained in (0, 1):
+        lib.check(lib.lib().gdpso_chain_debug(chained, 0, 1))
+        try:
+            gen = eng.PackedGenerator(synth.generator_state(10, 1, 64, seed=11), dev)
+            ass = eng.PackedAssessor(synth.resnet_state("ResNet50", 1, 8, seed=12), dev, img_side=28)
+            ev = eng.Evaluator(gen, ass)
+            z = torch.from_numpy(np.random.RandomState(4).standard_normal((512, 10))).cuda()
+            fit, _, _ = ev.fitness(z, eng.FitnessSpec(class_index=3))
+            res.append(fit.cpu().numpy().copy())
+        finally:
+            lib.check(lib.lib().gdpso_chain_debug(1, 0, 1))
+    np.testing.assert_array_equal(res[1], res[0])

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Where the chained launch spends its time, step by step (diagnostic build, tools/libgdpso_stamps.so:
+`python tools/stamp_probe.py build` here, then `python tools/chain_probe.py [n]` on the GPU).
+
+Per step (over the workgroups of XCD share 0 and over all): when the first / last workgroup entered, how
+long the waits lasted, how long the tiles took, and the hand-off: last signal of step s-1 -> last wait
+of step s ended."""
+import ctypes as C
+import importlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    eng = importlib.import_module("gan-discovery-pso_amd.engine")
+    synth = importlib.import_module("gan-discovery-pso_amd.synth")
+    _lib = importlib.import_module("gan-discovery-pso_amd._lib")
+    _lib.LIB_PATH = os.path.join(HERE, "libgdpso_stamps.so")  # the diagnostic build instead of the product library
+    lib = _lib.lib()
+    dev = torch.device("cuda:0")
+    ass = eng.PackedAssessor(synth.resnet_state("ResNet50", 1, 8, seed=12), dev, img_side=28)
+    gen = eng.PackedGenerator(synth.generator_state(10, 1, 64, seed=11), dev)
+    ev = eng.Evaluator(gen, ass)
+    x = torch.rand(n, 28, 28, device=dev)
+    for _ in range(3):
+        ev.assess(x, eng.FitnessSpec(class_index=0))
+    buf = torch.zeros(512, 192, 4, dtype=torch.int64, device=dev)
+    lib.gdpso_chain_stamps_set.argtypes = [C.c_void_p]
+    assert lib.gdpso_chain_stamps_set(buf.data_ptr()) == 0
+    ev.assess(x, eng.FitnessSpec(class_index=0))
+    torch.cuda.synchronize()
+    raw = buf.cpu().numpy().astype(np.int64)
+    ident = raw[:, 191, 0]
+    share = (ident & 0xff) - 1
+    s = raw * 0.01  # us
+    s[:, 191] = 0
+    t0 = s[s > 0].min()
+    nsteps = int(np.nonzero((s[:, :, 2] > 0).any(axis=0))[0].max()) + 1
+    print(f"{nsteps} steps; us; per step the median over the 8 shares of: workgroups with a tile, wait (enter -> wait ended), "
+          "tiles (wait end -> done; median and max over workgroups), drain + signal, hand-off (last signal of the previous step -> "
+          "last wait end), step (last signal -> last signal)")
+    print(" step  wgs    wait   tiles(med max)  signal  handoff    step")
+    tot = 0.0
+    for k in range(nsteps):
+        rows = []
+        for sh in range(8):
+            live = (s[:, k, 2] > 0) & (share == sh)
+            if not live.any():
+                continue
+            e, w, d, g = (s[live, k, i] for i in range(4))
+            start = np.where(w > 0, w, e)
+            prev = s[(share == sh), k - 1, 3].max() if k > 0 else e.min()
+            hand = (w.max() - prev) if k > 0 else 0.0
+            rows.append((live.sum(), np.median(start - e), np.median(d - start), (d - start).max(), np.median(g - d), hand, g.max() - prev))
+        r = np.median(np.array(rows, dtype=float), axis=0)
+        tot += r[6]
+        print(f" {k:3d}  {int(r[0]):4d}  {r[1]:6.2f}  {r[2]:6.2f} {r[3]:6.2f}  {r[4]:6.2f}  {r[5]:7.2f}  {r[6]:6.2f}")
+    print(f"sum of step times {tot:.2f} us; whole chain: {s.max() - t0:.2f} us")
+
+
+if __name__ == "__main__":
+    main()
