@@ -182,6 +182,10 @@ def main():
         return dry_run(args, world, rank, result_fd)
     # GDPSO_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the multi-rank path
     backend = os.environ.get("GDPSO_BENCH_BACKEND", "nccl")
+    if backend != "nccl" and world > 1:
+        # ranks that share one GPU: a chained launch needs all its workgroups resident at once, which two
+        # processes launching side by side cannot both have; one launch per layer there
+        os.environ.setdefault("GDPSO_CONV_CHAIN", "0")
     local_rank %= max(1, torch.cuda.device_count()) if backend != "nccl" else 1 << 30
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -302,7 +306,8 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
         peak = PEAK_MFMA_TFLOPS[args.dtype]
-        roofline = {"bound": "mfma", "kernel": f"conv_gemm_kernel / conv_gemm_pair_kernel / conv_gemm_fused_kernel, all instantiations ({args.dtype}-input MFMA implicit GEMM)",
+        roofline = {"bound": "mfma", "kernel": f"conv_chain_kernel (the ResNet stages behind the first in one persistent launch, fp32) / conv_gemm_kernel / conv_gemm_pair_kernel / "
+                              f"conv_gemm_fused_kernel, all instantiations: one tile code ({args.dtype}-input MFMA implicit GEMM)",
                     "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic,
                     "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/" + TRAFFIC_FILE + ")",

@@ -160,6 +160,9 @@ int chain_add(ConvChain *c, const ConvLayer *La, const ChainBuf &in, const Chain
               const ConvLayer *Lb = nullptr, const ChainBuf *out_b = nullptr);
 int chain_finish(ConvChain *c, size_t ctl_off);
 int launch_chain(const ConvChain *c, hipStream_t stream, void *workspace);
+// Called by every entry point that launches a network: tells whether `stream` is (still) the only
+// stream this library has launched on on the current device; chains run only while that holds.
+int chain_note_stream(hipStream_t stream, bool *single);
 
 // host-side helpers (pack.cpp)
 struct DeviceArena {

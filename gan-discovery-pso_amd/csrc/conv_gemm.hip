@@ -35,6 +35,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <atomic>
+#include <map>
+#include <mutex>
 
 #include "common.h"
 
@@ -101,14 +104,24 @@ struct ChainWait {
     unsigned *status = nullptr;
 #ifdef GDPSO_STAMPS
     unsigned long long *stamp = nullptr;  // diagnostic build: where to note the time the wait ended
+    unsigned long long *tile_stamps = nullptr;  // ... and where the tile code's own stamps go (null: not this tile)
 #endif
 };
-constexpr unsigned CHAIN_SPIN_LIMIT = 4000000;  // polls (each an L2 round trip): seconds
+// How long a wait may last, in s_memrealtime ticks (100 MHz).  The registration of all workgroups can
+// legitimately take long when kernels of other streams or processes hold compute units (the chain's
+// workgroups trickle in as those finish, and the ones already there keep their slots); a step's flags
+// come from workgroups that are all running.  Past these limits something is broken.
+constexpr unsigned long long CHAIN_REGISTER_TICKS = 2000000000ull;  // 20 s
+constexpr unsigned long long CHAIN_STEP_TICKS = 200000000ull;       // 2 s
 __device__ unsigned g_chain_aborts = 0;         // chains that gave up waiting since the library was loaded
+__device__ unsigned g_chain_abort_bits = 0;     // what they were waiting for: 1 a step's flags, 2 the registration of all workgroups
+__device__ unsigned g_chain_abort_arrived = 0;  // workgroups that had registered when a registration wait gave up
 
 __device__ __forceinline__ void chain_abort(unsigned *status, unsigned bit) {
-    if (__hip_atomic_fetch_or(status, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+    if (__hip_atomic_fetch_or(status, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
         __hip_atomic_fetch_add(&g_chain_aborts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_or(&g_chain_abort_bits, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // The first wave polls, one member's word per lane (agent-scope atomic loads: never served from the
@@ -119,6 +132,7 @@ __device__ __forceinline__ void chain_wait(const ChainWait &w, int tid) {
     if (w.flags == nullptr) return;
     if (tid < 64) {
         unsigned spins = 0;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         for (int base = 0; base < w.count; base += 64) {
             for (;;) {
                 const int m = base + tid;
@@ -127,7 +141,7 @@ __device__ __forceinline__ void chain_wait(const ChainWait &w, int tid) {
                 ++spins;
                 if ((spins & 255u) == 0) {
                     const unsigned st = __hip_atomic_load(w.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (__any((int)(st != 0 || spins > CHAIN_SPIN_LIMIT))) {
+                    if (__any((int)(st != 0 || __builtin_amdgcn_s_memrealtime() - t0 > CHAIN_STEP_TICKS))) {
                         if (tid == 0) chain_abort(w.status, 1u);
                         base = w.count;
                         break;
@@ -387,6 +401,11 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
     E *sB = sA + 2 * BM * LDA;
     const E *const in = (const E *)a.in;
 
+#ifdef GDPSO_STAMPS
+    // a chain stamps the tiles of one chosen step only; `g_stamps` below is then this pointer, already offset
+    // so that adding the workgroup's slot lands in its row
+    unsigned long long *const g_stamps = CHAIN ? (wait.tile_stamps ? wait.tile_stamps - (size_t)blockIdx.x * 16 : nullptr) : gdpso::g_stamps;
+#endif
     GDPSO_STAMP(0)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = KW == 1 ? wave >> 1 : 0, wc = KW == 4 ? 0 : wave & 1, kh = KW == 1 ? 0 : (KW == 2 ? wave >> 1 : wave);
@@ -590,7 +609,9 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
         if constexpr (CHAIN) {
             // weights first; the activations only once the layer that writes them has finished in this share
             GDPSO_GISSUE_B(0)
+            GDPSO_STAMP(11)  // weights requested, the wait begins
             chain_wait(wait, tid);
+            GDPSO_STAMP(12)
             GDPSO_GISSUE_A(0)
             GDPSO_GADVANCE()
         } else {
@@ -936,6 +957,7 @@ __device__ __forceinline__ ConvKArgs chain_load_args(const ChainStep *steps, int
 // Diagnostic build only (tools/chain_probe.py): per workgroup and step, s_memrealtime (100 MHz) when
 // the step was entered, when its wait ended, when its tiles were done and when it was signalled.
 __device__ unsigned long long *g_chain_stamps = nullptr;
+__device__ int g_chain_stamp_step = -1;  // the step whose tiles also leave the tile code's own stamps in g_stamps
 #endif
 
 __global__ __launch_bounds__(256, 2) void conv_chain_kernel(const ChainStep *steps, int nsteps, char *ws, ChainCtl *ctl,
@@ -960,15 +982,18 @@ __global__ __launch_bounds__(256, 2) void conv_chain_kernel(const ChainStep *ste
         __hip_atomic_fetch_add(&ctl->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
         bool ok = true;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         while (__hip_atomic_load(&ctl->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
             ++spins;
-            if ((spins & 255u) == 0 &&
-                (spins > CHAIN_SPIN_LIMIT || __hip_atomic_load(&ctl->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            if ((spins & 255u) == 0 && (__builtin_amdgcn_s_memrealtime() - t0 > CHAIN_REGISTER_TICKS ||
+                                        __hip_atomic_load(&ctl->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
                 chain_abort(&ctl->status, 2u);
+                __hip_atomic_fetch_max(&g_chain_abort_arrived, __hip_atomic_load(&ctl->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok = false;
                 break;
             }
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(8);
         }
         int populated = 0, rank = 0;
         unsigned m0 = 0, m1 = 0, m2 = 0;
@@ -1047,6 +1072,7 @@ __global__ __launch_bounds__(256, 2) void conv_chain_kernel(const ChainStep *ste
                     w.status = &ctl->status;
 #ifdef GDPSO_STAMPS
                     w.stamp = stamps ? stamps + 1 : nullptr;
+                    w.tile_stamps = (g_stamps && s == g_chain_stamp_step) ? g_stamps + (size_t)blockIdx.x * 16 : nullptr;
 #endif
                 }
                 if (!first) __syncthreads();  // the previous tile's store pass has left the LDS
@@ -1417,6 +1443,7 @@ static bool g_chain_enabled = [] {
     return e ? e[0] != '0' : true;
 }();
 static unsigned g_chain_drop_mask = 0;  // test aid, see gdpso_chain_debug
+static std::atomic<unsigned> g_chain_launches{0};
 // Teams per XCD (GDPSO_CHAIN_TEAMS=1|2) and, with two, how long the second starts after the first
 // (GDPSO_CHAIN_STAGGER_US), so that one team computes while the other hands over.
 static int g_chain_teams = [] {
@@ -1456,13 +1483,15 @@ void chain_free(ConvChain *c) { delete c; }
 int chain_steps(const ConvChain *c) { return c ? (int)c->steps.size() : 0; }
 
 // The tile shape a layer runs with as a step of a chain over `nshare` shares of the images (0: it cannot
-// be a step): fp32, unsplit, one of the three small shapes, and every phase's rows of one share fill
-// whole tiles.  The planner's shape if that holds for it, else the next smaller one.
+// be a step): fp32, one of the three small shapes, and every phase's rows of one share fill whole
+// tiles.  The planner's shape if that holds for it, else the next smaller one; a chain never splits K
+// over workgroups (the planner does when a layer alone has fewer tiles than the device has CUs).
 int chain_tile(const ConvLayer &L, int n_images, int nshare) {
-    if (L.dtype != DT_F32 || L.splits != 1 || n_images % nshare != 0) return 0;
+    if (L.dtype != DT_F32 || n_images % nshare != 0) return 0;
     const int order[3] = {64, 32, TILE_32x32};
     for (int t : order) {
-        if (tile_bm(t) > tile_bm(L.tile) || (tile_bm(t) == tile_bm(L.tile) && tile_bn(t) > tile_bn(L.tile))) continue;  // not larger than planned
+        // not larger than planned (a layer planned with 128x128 tiles is long enough to stand alone)
+        if (L.tile == 128 || tile_bm(t) > tile_bm(L.tile) || (tile_bm(t) == tile_bm(L.tile) && tile_bn(t) > tile_bn(L.tile))) continue;
         if (t == 32 && L.cin % 64 != 0) continue;
         if (t == TILE_32x32 && L.cin % 128 != 0) continue;
         if (L.cout % tile_bn(t) != 0) continue;
@@ -1515,6 +1544,7 @@ int chain_add(ConvChain *c, const ConvLayer *La, const ChainBuf &in, const Chain
     std::memset(&st, 0, sizeof(st));
     c->layers.push_back(*La);
     c->layers.back().tile = ta;
+    c->layers.back().splits = 1;
     int rc = chain_fill(*c, c->layers.back(), in, res, out_a, st, 0);
     if (rc) return rc;
     c->layer_has_res.push_back(res != nullptr);
@@ -1522,6 +1552,7 @@ int chain_add(ConvChain *c, const ConvLayer *La, const ChainBuf &in, const Chain
         if (!out_b) return fail(GDPSO_ERR_ARG, "chain: second layer without an output");
         c->layers.push_back(*Lb);
         c->layers.back().tile = tb;
+        c->layers.back().splits = 1;
         if ((rc = chain_fill(*c, c->layers.back(), in, nullptr, *out_b, st, 1))) return rc;
         c->layer_has_res.push_back(0);
     }
@@ -1542,6 +1573,41 @@ int chain_finish(ConvChain *c, size_t ctl_off) {
     c->ctl_off = ctl_off;
     GDPSO_HIP(hipMalloc(&c->dev_steps, c->steps.size() * sizeof(ChainStep)));
     GDPSO_HIP(hipMemcpy(c->dev_steps, c->steps.data(), c->steps.size() * sizeof(ChainStep), hipMemcpyHostToDevice));
+    return GDPSO_OK;
+}
+
+// A chain's workgroups wait for each other, so its grid must be resident as a whole, and the
+// workgroups that are already there hold their compute units while they wait for the rest.  Beside
+// kernels of another stream that is a bad neighbour: the others crawl through the few free slots, the
+// chain's last workgroups wait behind them (measured: half a second for what takes a millisecond), and
+// two chains side by side could each hold half of the device.  So a device runs chains only while
+// this library has seen a single stream on it: the entry points that launch networks report their
+// stream here, and once a second stream shows up the first is drained (once) and every later forward
+// pass on that device runs one launch per layer.  Kernels the caller launches on other streams
+// without the library's knowledge only slow a chain down.
+namespace {
+struct ChainStreams {
+    hipStream_t first = nullptr;
+    bool any = false, several = false;
+};
+std::mutex g_chain_streams_mutex;
+std::map<int, ChainStreams> g_chain_streams;  // by device
+}  // namespace
+
+int chain_note_stream(hipStream_t stream, bool *single) {
+    int dev = 0;
+    GDPSO_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_chain_streams_mutex);
+    ChainStreams &cs = g_chain_streams[dev];
+    if (!cs.any) {
+        cs.any = true;
+        cs.first = stream;
+    } else if (!cs.several && cs.first != stream) {
+        cs.several = true;
+        // (a stream the caller has destroyed in the meantime has nothing left to wait for)
+        if (hipStreamSynchronize(cs.first) != hipSuccess) (void)hipGetLastError();
+    }
+    if (single) *single = !cs.several;
     return GDPSO_OK;
 }
 
@@ -1568,6 +1634,7 @@ int launch_chain(const ConvChain *c, hipStream_t stream, void *workspace) {
                            g_chain_drop_mask, c->nteams, g_chain_stagger);
     }
     GDPSO_HIP(hipGetLastError());
+    ++g_chain_launches;
     return GDPSO_OK;
 }
 
@@ -1584,15 +1651,26 @@ extern "C" int gdpso_chain_debug(int enabled, unsigned drop_xcc_mask, int teams)
     g_chain_enabled = enabled != 0;
     g_chain_drop_mask = drop_xcc_mask & 0xffu;
     if (teams) g_chain_teams = teams;
+    {
+        std::lock_guard<std::mutex> lock(g_chain_streams_mutex);
+        g_chain_streams.clear();  // forget the streams seen so far (a test that used several on purpose)
+    }
     return GDPSO_OK;
 }
 
-// Chains that ran out of patience waiting for a step since the library was loaded (0 on a healthy
-// device).  Synchronises the device.
-extern "C" int gdpso_chain_aborts(unsigned *count) {
+// Chained launches since the library was loaded, and how many of them ran out of patience waiting for
+// their workgroups or for a step (0 on a healthy device).  Synchronises the device.
+extern "C" int gdpso_chain_stats(unsigned *launches, unsigned *count) {
     using namespace gdpso;
-    GDPSO_REQUIRE(count, "chain_aborts: null pointer");
+    GDPSO_REQUIRE(launches && count, "chain_stats: null pointer");
+    *launches = g_chain_launches.load();
     GDPSO_HIP(hipMemcpyFromSymbol(count, HIP_SYMBOL(g_chain_aborts), sizeof(unsigned)));
+    unsigned bits = 0;
+    GDPSO_HIP(hipMemcpyFromSymbol(&bits, HIP_SYMBOL(g_chain_abort_bits), sizeof(unsigned)));
+    unsigned arrived = 0;
+    GDPSO_HIP(hipMemcpyFromSymbol(&arrived, HIP_SYMBOL(g_chain_abort_arrived), sizeof(unsigned)));
+    if (*count) set_error("chain aborts: waited in vain for " + std::string(bits & 2 ? "the registration of all workgroups (" + std::to_string(arrived) + " had registered) " : "") +
+                          std::string(bits & 1 ? "a step's flags" : ""));
     return GDPSO_OK;
 }
 
@@ -1634,8 +1712,9 @@ extern "C" int gdpso_conv_stamps_set(void *device_buffer) {
     return GDPSO_OK;
 }
 // [workgroups][CHAIN_MAX_STEPS = 192][4] 64-bit stamps
-extern "C" int gdpso_chain_stamps_set(void *device_buffer) {
+extern "C" int gdpso_chain_stamps_set(void *device_buffer, int tile_step) {
     GDPSO_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gdpso::g_chain_stamps), &device_buffer, sizeof(void *)));
+    GDPSO_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gdpso::g_chain_stamp_step), &tile_step, sizeof(int)));
     return GDPSO_OK;
 }
 

@@ -764,6 +764,10 @@ extern "C" int gdpso_generator_forward(const gdpso_generator *g, void *stream_, 
     GDPSO_REQUIRE(n > 0, "generator_forward: n must be positive");
     GDPSO_REQUIRE((target == nullptr) == (mse == nullptr), "generator_forward: target and mse go together");
     hipStream_t stream = (hipStream_t)stream_;
+    {
+        int rc0 = chain_note_stream(stream, nullptr);  // (the assessor runs chained launches only beside a single stream)
+        if (rc0) return rc0;
+    }
     const std::shared_ptr<const GenLayout> plan = gen_layout(g, n);
     const GenLayout &L = *plan;
     const ConvLayer &l1 = L.l1, &l2 = L.l2;
@@ -1140,6 +1144,11 @@ static int assessor_forward_impl(const gdpso_assessor *a, void *stream_, int n, 
     GDPSO_REQUIRE(!fitness || a->n_class == 2 || class_per_image || (class_index >= 0 && class_index < a->n_class),
                   "assessor_forward: class_index out of range");
     hipStream_t stream = (hipStream_t)stream_;
+    bool single_stream = true;
+    {
+        int rc0 = chain_note_stream(stream, &single_stream);
+        if (rc0) return rc0;
+    }
     const std::shared_ptr<const AssLayout> plan = ass_layout(a, n);
     const AssLayout &L = *plan;
     if (workspace_bytes < L.total) return fail(GDPSO_ERR_WORKSPACE, "assessor_forward: workspace too small");
@@ -1187,9 +1196,10 @@ static int assessor_forward_impl(const gdpso_assessor *a, void *stream_, int n, 
     }
     int rc;
     if ((rc = conv_splitk_prepare(stream, sk))) return rc;
+    const bool use_chain = L.chain != nullptr && single_stream;
     for (size_t bi = 0; bi < L.blocks.size(); ++bi) {
         const Bottleneck &b = L.blocks[bi];
-        if (L.chain && (int)bi >= L.chain_first) {
+        if (use_chain && (int)bi >= L.chain_first) {
             if ((int)bi == L.chain_first && (rc = launch_chain(L.chain, stream, workspace))) return rc;
             x = ws + L.chain_out;  // (the remaining blocks are all part of the chain)
             continue;
@@ -1301,6 +1311,10 @@ extern "C" int gdpso_encoder_forward(const gdpso_encoder *e, void *stream_, int 
     GDPSO_REQUIRE(e && img && latent && workspace, "encoder_forward: null argument");
     GDPSO_REQUIRE(n > 0, "encoder_forward: n must be positive");
     hipStream_t stream = (hipStream_t)stream_;
+    {
+        int rc0 = chain_note_stream(stream, nullptr);  // (the assessor runs chained launches only beside a single stream)
+        if (rc0) return rc0;
+    }
     ConvLayer c2, c3;
     const EncLayout L = enc_layout(e, n, c2, c3);
     if (workspace_bytes < L.total) return fail(GDPSO_ERR_WORKSPACE, "encoder_forward: workspace too small");

@@ -99,6 +99,23 @@ def _state_dict_of(model):
 
 
 # ---------------------------------------------------------------------------- handles
+_chain_aborts_seen = 0
+
+
+def check_chains() -> None:
+    """Raises if a chained convolution launch (several dependent layers in one persistent kernel) gave up
+    waiting for a step since the last call: its outputs, and everything computed from them, are wrong.
+    That happens only when the launch's workgroups cannot all be resident (another process' kernels
+    holding compute units for seconds).  Synchronises the device."""
+    global _chain_aborts_seen
+    n, launches = C.c_uint(0), C.c_uint(0)
+    check(_lib.lib().gdpso_chain_stats(C.byref(launches), C.byref(n)))
+    if n.value != _chain_aborts_seen:
+        _chain_aborts_seen = n.value
+        raise _lib.GdpsoError("a chained convolution launch timed out waiting for its workgroups; results since the last check are invalid "
+                         "(set GDPSO_CONV_CHAIN=0 to run one launch per layer)")
+
+
 class _Handle:
     _destroy = None
 
@@ -475,7 +492,9 @@ class HipSwarm:
 
     # -- read-back
     def control(self) -> np.ndarray:
-        return self.ctrl.cpu().numpy()
+        c = self.ctrl.cpu().numpy()
+        check_chains()
+        return c
 
     def results(self) -> dict:
         """Everything the reference's Swarm exposes after optimize(), as numpy arrays."""

@@ -352,13 +352,16 @@ unsigned gdpso_fast_div_check(unsigned n, unsigned d);
  * and tests); drop_xcc_mask: workgroups on these XCDs (bits 0-7, not all) stand aside, which exercises the
  * path for an uneven deal of workgroups to XCDs (a test aid; results do not change); teams (0: keep,
  * 1, 2): teams of workgroups per XCD in plans made from now on (two teams each own a sixteenth of the
- * images and walk the layers independently; measured slower than one on MI355X, kept as an A/B switch). */
+ * images and walk the layers independently; measured slower than one on MI355X, kept as an A/B switch).
+ * Chains run on a device only while the library has seen a single stream there;
+ * every call also forgets the streams seen so far. */
 int gdpso_chain_debug(int enabled, unsigned drop_xcc_mask, int teams);
 
-/* No counterpart in the reference: number of chained launches since the library was loaded that gave up
- * waiting for a step (0 on a healthy device; such a launch ends with wrong results instead of hanging).
- * Synchronises the device. */
-int gdpso_chain_aborts(unsigned *count);
+/* No counterpart in the reference: chained launches since the library was loaded, and how many of them
+ * gave up waiting for their workgroups or for a step (0 on a healthy device; such a launch ends with
+ * wrong results instead of hanging, and gdpso_last_error() says what it waited for).  Synchronises
+ * the device. */
+int gdpso_chain_stats(unsigned *launches, unsigned *aborts);
 
 /* No counterpart in the reference: times one ksize x ksize convolution layer in isolation
  * on random data (allocates and frees its own buffers; a development / tuning aid).

@@ -23,10 +23,14 @@ def lib():
     return importlib.import_module("gan-discovery-pso_amd._lib")
 
 
+def _stats(lib):
+    launches, aborts = C.c_uint(0), C.c_uint(0)
+    lib.check(lib.lib().gdpso_chain_stats(C.byref(launches), C.byref(aborts)))
+    return launches.value, aborts.value
+
+
 def _aborts(lib):
-    c = C.c_uint(0)
-    lib.check(lib.lib().gdpso_chain_aborts(C.byref(c)))
-    return c.value
+    return _stats(lib)[1]
 
 
 def _logits(eng, lib, synth, model, n, side, chained, drop=0, seed=5, teams=1):
@@ -39,10 +43,12 @@ def _logits(eng, lib, synth, model, n, side, chained, drop=0, seed=5, teams=1):
         ev = eng.Evaluator(gen, ass)
         x = torch.from_numpy(np.random.RandomState(seed).random_sample((n, side, side)).astype(np.float32)).cuda()
         out = []
+        launched = _stats(lib)[0]
         for _ in range(3):  # the same buffers again: stale cache lines would show on the second pass
             _, logits = ev.assess(x, eng.FitnessSpec(class_index=0), want_logits=True)
             out.append(logits.cpu().numpy().copy())
         torch.cuda.synchronize()
+        assert _stats(lib)[0] - launched == (3 if chained else 0)  # the path under test is the one that ran
     finally:
         lib.check(lib.lib().gdpso_chain_debug(1, 0, 1))
     for o in out[1:]:
@@ -50,13 +56,18 @@ def _logits(eng, lib, synth, model, n, side, chained, drop=0, seed=5, teams=1):
     return out[0], x
 
 
-@pytest.mark.parametrize("model,n,side", [("ResNet50", 512, 28), ("ResNet50", 256, 28), ("ResNet50", 1024, 28),
-                                           ("ResNet101", 512, 28), ("ResNet50", 512, 64)])
-def test_chain_matches_per_layer_launches(eng, lib, synth, model, n, side):
+@pytest.mark.parametrize("model,n,side,exact", [("ResNet50", 512, 28, True), ("ResNet50", 256, 28, False), ("ResNet50", 1024, 28, True),
+                                                 ("ResNet101", 512, 28, True)])
+def test_chain_matches_per_layer_launches(eng, lib, synth, model, n, side, exact):
+    """exact: the per-layer plan has no split-K layer at this size, so both paths add in the same order (at
+    256 images the late stages alone have fewer tiles than the device has CUs and are split; a chain never is)."""
     before = _aborts(lib)
     plain, _ = _logits(eng, lib, synth, model, n, side, chained=False)
     chained, _ = _logits(eng, lib, synth, model, n, side, chained=True)
-    np.testing.assert_array_equal(chained, plain)
+    if exact:
+        np.testing.assert_array_equal(chained, plain)
+    else:
+        np.testing.assert_allclose(chained, plain, rtol=1e-4, atol=2e-4)
     assert _aborts(lib) == before
 
 
@@ -106,3 +117,36 @@ def test_swarm_run_is_the_same_chained(eng, lib, synth):
         finally:
             lib.check(lib.lib().gdpso_chain_debug(1, 0, 1))
     np.testing.assert_array_equal(res[1], res[0])
+
+
+def test_chains_on_two_streams(eng, lib, synth):
+    """Two evaluators on two streams, launches interleaved from the host: once the library sees a second
+    stream on the device it stops chaining there (a chain's workgroups hold their compute units while they
+    wait for each other: a bad neighbour for another stream's kernels); results are those of either
+    evaluator alone."""
+    dev = torch.device("cuda:0")
+    lib.check(lib.lib().gdpso_chain_debug(1, 0, 1))
+    before = _aborts(lib)
+    gen = eng.PackedGenerator(synth.generator_state(10, 1, 64, seed=11), dev)
+    ass = eng.PackedAssessor(synth.resnet_state("ResNet50", 1, 8, seed=12), dev, img_side=28)
+    evs = [eng.Evaluator(gen, ass), eng.Evaluator(gen, ass)]
+    z = [torch.from_numpy(np.random.RandomState(s).standard_normal((512, 10))).cuda() for s in (1, 2)]
+    spec = eng.FitnessSpec(class_index=2)
+    want = [evs[i].fitness(z[i], spec)[0].cpu().numpy().copy() for i in range(2)]
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    torch.cuda.synchronize()
+    got = [None, None]
+    for rep in range(3):
+        for i in range(2):
+            with torch.cuda.stream(streams[i]):
+                got[i] = evs[i].fitness(z[i], spec)[0]
+    torch.cuda.synchronize()
+    launched = _stats(lib)[0]
+    with torch.cuda.stream(streams[0]):
+        evs[0].fitness(z[0], spec)
+    torch.cuda.synchronize()
+    assert _stats(lib)[0] == launched  # a device that has seen two streams runs one launch per layer
+    lib.check(lib.lib().gdpso_chain_debug(1, 0, 1))  # forget the streams: the tests behind this one chain again
+    for i in range(2):
+        np.testing.assert_array_equal(got[i].cpu().numpy(), want[i])
+    assert _aborts(lib) == before

@@ -33,8 +33,12 @@ def main():
     for _ in range(3):
         ev.assess(x, eng.FitnessSpec(class_index=0))
     buf = torch.zeros(512, 192, 4, dtype=torch.int64, device=dev)
-    lib.gdpso_chain_stamps_set.argtypes = [C.c_void_p]
-    assert lib.gdpso_chain_stamps_set(buf.data_ptr()) == 0
+    tile_step = int(sys.argv[2]) if len(sys.argv) > 2 else -1
+    tbuf = torch.zeros(8192, 16, dtype=torch.int64, device=dev)  # (the other convolution kernels stamp their workgroups' rows too)
+    lib.gdpso_chain_stamps_set.argtypes = [C.c_void_p, C.c_int]
+    lib.gdpso_conv_stamps_set.argtypes = [C.c_void_p]
+    assert lib.gdpso_conv_stamps_set(tbuf.data_ptr()) == 0
+    assert lib.gdpso_chain_stamps_set(buf.data_ptr(), tile_step) == 0
     ev.assess(x, eng.FitnessSpec(class_index=0))
     torch.cuda.synchronize()
     raw = buf.cpu().numpy().astype(np.int64)
@@ -64,6 +68,18 @@ def main():
         tot += r[6]
         print(f" {k:3d}  {int(r[0]):4d}  {r[1]:6.2f}  {r[2]:6.2f} {r[3]:6.2f}  {r[4]:6.2f}  {r[5]:7.2f}  {r[6]:6.2f}")
     print(f"sum of step times {tot:.2f} us; whole chain: {s.max() - t0:.2f} us")
+    if tile_step >= 0:
+        # the tile code's own stamps (s_memtime ticks; slots 7 / 6 hold s_memrealtime at entry / exit) of the first tile
+        # each workgroup ran in that step
+        ts = tbuf.cpu().numpy().astype(np.int64)
+        ts = ts[ts[:, 11] != 0]  # rows stamped by the chain (only it has slot 11)
+        ghz = float(np.median((ts[:, 3] - ts[:, 0]) / np.maximum(1, (ts[:, 6] - ts[:, 7]) * 10.0)))
+        print(f"step {tile_step}: {ts.shape[0]} workgroups stamped, in-kernel clock ~{ghz:.2f} GHz; medians (p90) in us:")
+        for name, a, b in (("entry -> phase header in SGPRs", 0, 8), ("-> weights requested (wait begins)", 8, 11), ("wait", 11, 12),
+                           ("-> activations requested", 12, 9), ("-> returned", 9, 10), ("-> LDS stores + barrier", 10, 1),
+                           ("K loop", 1, 2), ("epilogue -> stores drained", 2, 3)):
+            v = (ts[:, b] - ts[:, a]) / (ghz * 1e3)
+            print(f"   {name:38s} {np.median(v):6.2f} ({np.percentile(v, 90):6.2f})")
 
 
 if __name__ == "__main__":

@@ -69,7 +69,7 @@ def main():
         tf = flop / avg_ns[k] / 1e3
         out["kernels"][k] = {"launches_counted": n[k], "avg_us": round(avg_ns[k] / 1e3, 2), "executed_gflop_per_launch": round(flop / 1e9, 3),
                              "executed_tflops": round(tf, 1), "mfma_util": round(tf / p, 3)}
-        if "conv_gemm" in k:
+        if "conv_gemm" in k or "conv_chain" in k:
             tot_flop += flop * n[k]
             tot_ns += avg_ns[k] * n[k]
     out["kernels"]["conv_gemm (all instantiations)"] = {"executed_tflops": round(tot_flop / tot_ns / 1e3, 1),

@@ -32,12 +32,12 @@ def main():
     for a in (fe, wr):
         tot = [0, 0.0]
         for k in list(a):
-            if "conv_gemm" in k:
+            if "conv_gemm" in k or "conv_chain" in k:
                 tot[0] += a[k][0]
                 tot[1] += a[k][1]
         a["conv_gemm (all instantiations)"] = tot
     for k in fe:
-        if fe[k][1] <= 0 or not (k.startswith("gdpso::") or k.startswith("conv_gemm")):
+        if fe[k][1] <= 0 or not (k.startswith("gdpso::") or k.startswith("conv_gemm") or k.startswith("conv_chain")):
             continue
         c, v = fe[k]
         cw, vw = wr.get(k, [c, 0.0])
