@@ -238,13 +238,21 @@ __device__ __forceinline__ void conv_store_plan(const ConvKArgs &a, int tid, int
         const bool want = a.splits == 1 && a.res != nullptr;
         if constexpr (CHAIN) {
             // written earlier in this launch by a workgroup of the same XCD: read past the L1 (sc1)
-            static_assert(is_f32<E>(), "chains run in fp32");
-            const __amdgpu_buffer_rsrc_t rsrc_res = __builtin_amdgcn_make_buffer_rsrc((void *)a.res, 0, (int)(a.slab * 4), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsrc_res = __builtin_amdgcn_make_buffer_rsrc((void *)a.res, 0, (int)(a.slab * sizeof(E)), 0x00020000);
 #pragma unroll
             for (int pass = 0; pass < Plan::PASSES; ++pass) {
                 sp.rres[pass] = 0.f;
-                if (want)
-                    sp.rres[pass] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_res, (sp.off[pass] < 0 ? col : sp.off[pass]) * 4, 0, 16 /* sc1 */));
+                if (want) {
+                    const int boff = (sp.off[pass] < 0 ? col : sp.off[pass]) * (int)sizeof(E);
+                    if constexpr (is_f32<E>()) {
+                        sp.rres[pass] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_res, boff, 0, 16 /* sc1 */));
+                    } else {  // four 16-bit elements
+                        using V = __attribute__((ext_vector_type(4))) E;
+                        using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
+                        const V v = __builtin_bit_cast(V, (u32x2)__builtin_amdgcn_raw_buffer_load_b64(rsrc_res, boff, 0, 16 /* sc1 */));
+                        sp.rres[pass] = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+                    }
+                }
             }
         } else {
 #pragma unroll
@@ -960,6 +968,7 @@ __device__ unsigned long long *g_chain_stamps = nullptr;
 __device__ int g_chain_stamp_step = -1;  // the step whose tiles also leave the tile code's own stamps in g_stamps
 #endif
 
+template <typename E>
 __global__ __launch_bounds__(256, 2) void conv_chain_kernel(const ChainStep *steps, int nsteps, char *ws, ChainCtl *ctl,
                                                              unsigned drop_xcc_mask, int nteams, unsigned stagger_ticks) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 64 * 132];  // the largest of the three tile shapes
@@ -1078,11 +1087,11 @@ __global__ __launch_bounds__(256, 2) void conv_chain_kernel(const ChainStep *ste
                 if (!first) __syncthreads();  // the previous tile's store pass has left the LDS
                 const ConvKArgs a = chain_load_args(steps, s, which, ws, share);
                 if (shape == 64)
-                    conv_tile<float, 64, 64, 32, 1, false, true>(a, share, slot, lds, nullptr, w);
+                    conv_tile<E, 64, 64, 128 / (int)sizeof(E), 1, false, true>(a, share, slot, lds, nullptr, w);
                 else if (shape == 32)
-                    conv_tile<float, 32, 64, 64, 2, false, true>(a, share, slot, lds, nullptr, w);
+                    conv_tile<E, 32, 64, 256 / (int)sizeof(E), 2, false, true>(a, share, slot, lds, nullptr, w);
                 else
-                    conv_tile<float, 32, 32, 128, 4, false, true>(a, share, slot, lds, nullptr, w);
+                    conv_tile<E, 32, 32, 512 / (int)sizeof(E), 4, false, true>(a, share, slot, lds, nullptr, w);
                 first = false;
             }
             if (!first) {
@@ -1462,6 +1471,7 @@ struct ConvChain {
     std::vector<char> layer_has_res;
     int n_images = 0;
     int nteams = 1;   // teams per XCD: 8 * nteams shares
+    int dtype = -1;   // of every layer (set by the first)
     int nshare() const { return 8 * nteams; }
     void *dev_steps = nullptr;
     size_t ctl_off = 0;
@@ -1483,17 +1493,18 @@ void chain_free(ConvChain *c) { delete c; }
 int chain_steps(const ConvChain *c) { return c ? (int)c->steps.size() : 0; }
 
 // The tile shape a layer runs with as a step of a chain over `nshare` shares of the images (0: it cannot
-// be a step): fp32, one of the three small shapes, and every phase's rows of one share fill whole
+// be a step): one of the three small shapes, and every phase's rows of one share fill whole
 // tiles.  The planner's shape if that holds for it, else the next smaller one; a chain never splits K
 // over workgroups (the planner does when a layer alone has fewer tiles than the device has CUs).
 int chain_tile(const ConvLayer &L, int n_images, int nshare) {
-    if (L.dtype != DT_F32 || n_images % nshare != 0) return 0;
+    if (!dtype_ok(L.dtype) || n_images % nshare != 0) return 0;
+    const int kq = dtype_kquant(L.dtype);  // k per wave per K-tile: the K-split tiles need 2 and 4 of them per tap
     const int order[3] = {64, 32, TILE_32x32};
     for (int t : order) {
         // not larger than planned (a layer planned with 128x128 tiles is long enough to stand alone)
         if (L.tile == 128 || tile_bm(t) > tile_bm(L.tile) || (tile_bm(t) == tile_bm(L.tile) && tile_bn(t) > tile_bn(L.tile))) continue;
-        if (t == 32 && L.cin % 64 != 0) continue;
-        if (t == TILE_32x32 && L.cin % 128 != 0) continue;
+        if (t == 32 && L.cin % (2 * kq) != 0) continue;
+        if (t == TILE_32x32 && L.cin % (4 * kq) != 0) continue;
         if (L.cout % tile_bn(t) != 0) continue;
         bool ok = true;
         for (int p = 0; p < L.nphase && ok; ++p)
@@ -1509,7 +1520,7 @@ static int chain_gap(const ConvChain &c, const ChainBuf &b, long pixels, int cha
     *gap = 0;
     if (b.bytes == 0) return GDPSO_OK;
     const size_t slice = b.bytes / c.nshare() / 16 * 16;
-    const size_t share_bytes = (size_t)(c.n_images / c.nshare()) * pixels * channels * sizeof(float);
+    const size_t share_bytes = (size_t)(c.n_images / c.nshare()) * pixels * channels * dtype_size(c.dtype);
     if (slice < share_bytes || slice - share_bytes > 0xffffffffu) return fail(GDPSO_ERR_ARG, "chain: buffer too small for a layer's share");
     *gap = (unsigned)(slice - share_bytes);
     return GDPSO_OK;
@@ -1540,6 +1551,8 @@ int chain_add(ConvChain *c, const ConvLayer *La, const ChainBuf &in, const Chain
     if ((int)c->steps.size() >= CHAIN_MAX_STEPS) return fail(GDPSO_ERR_ARG, "chain: too many steps");
     const int ta = chain_tile(*La, c->n_images, c->nshare()), tb = Lb ? chain_tile(*Lb, c->n_images, c->nshare()) : 1;
     if (!ta || !tb) return fail(GDPSO_ERR_ARG, "chain: layer cannot be chained at this batch size");
+    if (c->dtype < 0) c->dtype = La->dtype;
+    if (La->dtype != c->dtype || (Lb && Lb->dtype != c->dtype)) return fail(GDPSO_ERR_ARG, "chain: layers of different element types");
     ChainStep st;
     std::memset(&st, 0, sizeof(st));
     c->layers.push_back(*La);
@@ -1566,7 +1579,7 @@ int chain_finish(ConvChain *c, size_t ctl_off) {
     int dev = 0, cus = 0, occ = 0;
     GDPSO_HIP(hipGetDevice(&dev));
     GDPSO_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    GDPSO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_chain_kernel, 256, 0));
+    GDPSO_WITH_DTYPE(c->dtype, GDPSO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_chain_kernel<E>, 256, 0)));
     if (occ < 1) return fail(GDPSO_ERR_HIP, "chain: the kernel does not fit a compute unit");
     c->grid = cus * std::min(occ, 2);
     if (c->grid > CHAIN_MAX_MEMBERS) return fail(GDPSO_ERR_ARG, "chain: more workgroups than the control block holds");
@@ -1618,9 +1631,9 @@ int launch_chain(const ConvChain *c, hipStream_t stream, void *workspace) {
     const bool timed = g_timing.on && g_timing.used + 2 <= g_timing.events.size();
     const dim3 grid((unsigned)c->grid);
     if (timed) {
-        hipExtLaunchKernelGGL(conv_chain_kernel, grid, dim3(256), 0, stream, g_timing.events[g_timing.used],
-                              g_timing.events[g_timing.used + 1], 0, (const ChainStep *)c->dev_steps, (int)c->steps.size(), ws, ctl,
-                              g_chain_drop_mask, c->nteams, g_chain_stagger);
+        GDPSO_WITH_DTYPE(c->dtype, hipExtLaunchKernelGGL(conv_chain_kernel<E>, grid, dim3(256), 0, stream, g_timing.events[g_timing.used],
+                                                         g_timing.events[g_timing.used + 1], 0, (const ChainStep *)c->dev_steps,
+                                                         (int)c->steps.size(), ws, ctl, g_chain_drop_mask, c->nteams, g_chain_stagger));
         g_timing.used += 2;
         size_t li = 0;
         for (const ChainStep &st : c->steps)
@@ -1630,8 +1643,8 @@ int launch_chain(const ConvChain *c, hipStream_t stream, void *workspace) {
                     ++li;
                 }
     } else {
-        hipLaunchKernelGGL(conv_chain_kernel, grid, dim3(256), 0, stream, (const ChainStep *)c->dev_steps, (int)c->steps.size(), ws, ctl,
-                           g_chain_drop_mask, c->nteams, g_chain_stagger);
+        GDPSO_WITH_DTYPE(c->dtype, hipLaunchKernelGGL(conv_chain_kernel<E>, grid, dim3(256), 0, stream, (const ChainStep *)c->dev_steps,
+                                                      (int)c->steps.size(), ws, ctl, g_chain_drop_mask, c->nteams, g_chain_stagger));
     }
     GDPSO_HIP(hipGetLastError());
     ++g_chain_launches;

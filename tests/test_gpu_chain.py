@@ -33,13 +33,13 @@ def _aborts(lib):
     return _stats(lib)[1]
 
 
-def _logits(eng, lib, synth, model, n, side, chained, drop=0, seed=5, teams=1):
+def _logits(eng, lib, synth, model, n, side, chained, drop=0, seed=5, teams=1, dtype="f32"):
     """Logits of `n` seeded images through a fresh assessor whose plans are made with the switch set."""
     dev = torch.device("cuda:0")
     lib.check(lib.lib().gdpso_chain_debug(int(chained), drop, teams))
     try:
-        ass = eng.PackedAssessor(synth.resnet_state(model, 1, 8, seed=12), dev, img_side=side)
-        gen = eng.PackedGenerator(synth.generator_state(10, 1, 64, seed=11, first_kernel=side // 4), dev)
+        ass = eng.PackedAssessor(synth.resnet_state(model, 1, 8, seed=12), dev, img_side=side, dtype=dtype)
+        gen = eng.PackedGenerator(synth.generator_state(10, 1, 64, seed=11, first_kernel=side // 4), dev, dtype=dtype)
         ev = eng.Evaluator(gen, ass)
         x = torch.from_numpy(np.random.RandomState(seed).random_sample((n, side, side)).astype(np.float32)).cuda()
         out = []
@@ -68,6 +68,16 @@ def test_chain_matches_per_layer_launches(eng, lib, synth, model, n, side, exact
         np.testing.assert_array_equal(chained, plain)
     else:
         np.testing.assert_allclose(chained, plain, rtol=1e-4, atol=2e-4)
+    assert _aborts(lib) == before
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_chain_16bit_matches_per_layer_launches(eng, lib, synth, dtype):
+    """16-bit storage: the chained launch runs the same tiles in the same order as the launches per layer."""
+    before = _aborts(lib)
+    plain, _ = _logits(eng, lib, synth, "ResNet50", 512, 28, chained=False, dtype=dtype)
+    chained, _ = _logits(eng, lib, synth, "ResNet50", 512, 28, chained=True, dtype=dtype)
+    np.testing.assert_array_equal(chained, plain)
     assert _aborts(lib) == before
 
 
