@@ -901,27 +901,28 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_pair_kernel(const ConvKArgs 
 
 // ----------------------------------------------------------------------------- layer chains
 // A run of dependent layers in ONE launch.  Rows of different images never interact, so the images
-// are cut into 8 shares and every XCD walks the whole run for its share: producer and consumer of
-// every intermediate sit on the same XCD, the hand-off between two layers is a store drain, one L2
-// atomic and an L1-bypassing load (about 2 us, measured by tools/micro/xcd_barrier.hip; a hand-off
-// that crosses XCDs needs an L2 write-back and costs twenty times that), and the launch, argument
-// fetch and weight-load latency of every layer but the first disappear behind the previous layer.
+// are cut into 8 shares (16 with two teams per XCD) and every XCD walks the whole run for its share:
+// producer and consumer of every intermediate sit on the same XCD, and the hand-off between two
+// layers is a store drain, a plain store of the step number into the workgroup's own word of a flag
+// array and, on the other side, one wave polling that array and activation loads that miss the L1
+// and hit the XCD's L2 (about 1.5 us a round, measured by tools/micro/xcd_barrier.hip; a hand-off
+// that crosses XCDs needs an L2 write-back and costs twenty-five times that).  The launch gaps between
+// the layers and the skew of their fill and drain disappear.
 //
 // The grid is resident as a whole (the host sizes it from the occupancy query).  Workgroups find out
-// where they run from the hardware's XCC_ID, register, and wait until everybody has: after that each
-// knows how many workgroups every XCD got.  Populated XCDs take the shares in turn (XCD of rank r
-// among P takes shares r, r + P, ...: with the usual even deal, one each), the members of an XCD split
-// each step's tiles statically (member j takes tiles j, j + members, ...), publish the step in a word of their own
-// after their last tile and wait for the previous step's counter ahead of their first.  Nothing
-// depends on how the dispatcher deals workgroups to XCDs except the speed.
+// where they run from the hardware's XCC_ID and CU id, register, and wait until everybody has: after
+// that each knows how many workgroups every XCD got.  Populated XCDs take the shares in turn (XCD of
+// rank r among P takes shares r, r + P, ...: with the usual even deal, one each), the members of an XCD
+// split each step's tiles statically (member j takes tiles j, j + members, ...), publish the step in
+// their flag word after their last tile and wait for the previous step's flags ahead of their first.
+// Nothing depends on how the dispatcher deals workgroups to XCDs except the speed.
 constexpr int CHAIN_MAX_STEPS = 192;  // ResNet152 behind its first stage: 47 blocks x 3
 constexpr int CHAIN_MAX_SHARES = 16;  // 8 XCDs x up to two teams
 constexpr int CHAIN_MAX_MEMBERS = 1024;  // workgroups of one launch (all of them may land on one XCD)
 
-//
 // An address must not be written by two XCDs in one launch (two L2s would each hold a dirty copy and
 // the order of their write-backs decides what memory ends up with), and nothing a slower XCD still
-// has to read may be overwritten by a faster one.  So every buffer a chain writes is cut into 8 fixed
+// has to read may be overwritten by a faster one.  So every buffer a chain writes is cut into fixed
 // slices, one per share, whatever the layer: share s keeps its rows of every intermediate at
 // slice s (`gap` = slice size - the layer's bytes per share, added to the base once per share), the
 // chain's input is only read, and its final output has a buffer of its own.

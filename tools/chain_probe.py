@@ -55,7 +55,7 @@ def main():
     tot = 0.0
     for k in range(nsteps):
         rows = []
-        for sh in range(8):
+        for sh in range(16):
             live = (s[:, k, 2] > 0) & (share == sh)
             if not live.any():
                 continue
@@ -69,6 +69,14 @@ def main():
         print(f" {k:3d}  {int(r[0]):4d}  {r[1]:6.2f}  {r[2]:6.2f} {r[3]:6.2f}  {r[4]:6.2f}  {r[5]:7.2f}  {r[6]:6.2f}")
     print(f"sum of step times {tot:.2f} us; whole chain: {s.max() - t0:.2f} us")
     if tile_step >= 0:
+        # who is slow: the step's tile times of share 0 by member (members m and 63 - m share a CU)
+        member = (ident >> 8) & 0xffff
+        live = (s[:, tile_step, 2] > 0) & (share == 0)
+        order = np.argsort(member[live])
+        tt = (s[live, tile_step, 2] - np.where(s[live, tile_step, 1] > 0, s[live, tile_step, 1], s[live, tile_step, 0]))[order]
+        print(f"step {tile_step}, share 0: tile time by member:", " ".join(f"{v:.1f}" for v in tt))
+        done = (s[live, tile_step, 2] - s[live, tile_step, 2].min())[order]
+        print(f"step {tile_step}, share 0: finished after the first by:", " ".join(f"{v:.1f}" for v in done))
         # the tile code's own stamps (s_memtime ticks; slots 7 / 6 hold s_memrealtime at entry / exit) of the first tile
         # each workgroup ran in that step
         ts = tbuf.cpu().numpy().astype(np.int64)
