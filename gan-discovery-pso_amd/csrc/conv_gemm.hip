@@ -1780,6 +1780,24 @@ extern "C" int gdpso_conv_plan_describe(int n_images, int hin, int cin, int cout
     return (int)v.size();
 }
 
+// The tile a layer would run with as a step of a chained launch at this batch size (0: it cannot be a
+// step), after the planner's own choice for the layer alone.  Host only.
+extern "C" int gdpso_chain_tile_describe(int n_images, int hin, int cin, int cout, int ksize, int stride, int pad, int num_cus,
+                                         int teams, int dtype) {
+    using namespace gdpso;
+    if (!(n_images > 0 && hin > 0 && cin > 0 && cout > 0 && num_cus > 0 && ksize > 0 && stride > 0 && pad >= 0 && hin + 2 * pad >= ksize &&
+          conv_window_fits(ksize, pad) && (teams == 1 || teams == 2) && dtype_ok(dtype))) {
+        set_error("chain_tile_describe: bad argument");
+        return -GDPSO_ERR_ARG;
+    }
+    ConvLayer L;
+    std::vector<float> packed, w((size_t)cout * cin * ksize * ksize, 0.f);
+    make_conv(L, w.data(), cout, cin, ksize, ksize, stride, pad, hin, hin, ACT_NONE, packed);
+    L.dtype = dtype;
+    if (plan_conv(L, n_images, num_cus)) return -GDPSO_ERR_ARG;
+    return chain_tile(L, n_images, 8 * teams);
+}
+
 // Times one convolution layer in isolation (development / tuning aid): random weights and
 // inputs, `reps` back-to-back launches bracketed by HIP events.  tile = 0 / splits = 0 keep
 // the planner's choice.
