@@ -4,12 +4,17 @@ plan -- bit for bit, the tile code and the summation order are the same -- and a
 with an even deal of workgroups to XCDs and with XCDs standing aside (the uneven-deal path)."""
 import ctypes as C
 import importlib
+import os
 
 import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+# The development switch that takes the small tiles away (tools/switch_matrix.sh) changes which layers
+# can be chained and makes the per-layer plan split K in the late stages: these comparisons assume the
+# default tile set.
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("GDPSO_CONV_TILE32", "1") == "0", reason="assumes the default tile set")]
 TOL = 1e-4
 
 

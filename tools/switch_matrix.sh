@@ -16,4 +16,6 @@ run GDPSO_CONV_PAIR=0 GDPSO_CONV_FUSE_1X1=0
 run GDPSO_GEN_LAST_MFMA=0 GDPSO_STEM_MFMA=0
 run GDPSO_SPLITK_FUSED_MAX=8 GDPSO_CONV_TILE32=0
 run GDPSO_CONV_SNAKE=0
+run GDPSO_CONV_CHAIN=0
+run GDPSO_CHAIN_TEAMS=2
 cat $OUT
