@@ -62,9 +62,10 @@ def _logits(eng, lib, synth, model, n, side, chained, drop=0, seed=5, teams=1, d
 
 
 @pytest.mark.parametrize("model,n,side,exact", [("ResNet50", 512, 28, True), ("ResNet50", 256, 28, False), ("ResNet50", 1024, 28, True),
-                                                 ("ResNet101", 512, 28, True)])
+                                                 ("ResNet101", 512, 28, True), ("ResNet50", 768, 28, False), ("ResNet152", 512, 28, True)])
 def test_chain_matches_per_layer_launches(eng, lib, synth, model, n, side, exact):
-    """exact: the per-layer plan has no split-K layer at this size, so both paths add in the same order (at
+    """768 images: 96 a share, so the layers planned with 64-row tiles run with 32-row ones in the chain.
+    exact: the per-layer plan has no split-K layer at this size, so both paths add in the same order (at
     256 images the late stages alone have fewer tiles than the device has CUs and are split; a chain never is)."""
     before = _aborts(lib)
     plain, _ = _logits(eng, lib, synth, model, n, side, chained=False)
