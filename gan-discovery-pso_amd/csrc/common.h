@@ -159,7 +159,9 @@ bool chain_layer_ok(const ConvLayer &L, int n_images, int nteams);
 int chain_add(ConvChain *c, const ConvLayer *La, const ChainBuf &in, const ChainBuf *res, const ChainBuf &out_a,
               const ConvLayer *Lb = nullptr, const ChainBuf *out_b = nullptr);
 int chain_finish(ConvChain *c, size_t ctl_off);
-int launch_chain(const ConvChain *c, hipStream_t stream, void *workspace);
+// ctl_cleared: an earlier kernel on the same stream has zeroed the control block (chain_ctl_bytes() at the
+// offset given to chain_finish) since the chain last ran on this workspace; else a memset is enqueued first.
+int launch_chain(const ConvChain *c, hipStream_t stream, void *workspace, bool ctl_cleared = false);
 // Called by every entry point that launches a network: tells whether `stream` is (still) the only
 // stream this library has launched on on the current device; chains run only while that holds.
 int chain_note_stream(hipStream_t stream, bool *single);

@@ -1625,10 +1625,11 @@ int chain_note_stream(hipStream_t stream, bool *single) {
     return GDPSO_OK;
 }
 
-int launch_chain(const ConvChain *c, hipStream_t stream, void *workspace) {
+int launch_chain(const ConvChain *c, hipStream_t stream, void *workspace, bool ctl_cleared) {
     char *ws = (char *)workspace;
     ChainCtl *ctl = (ChainCtl *)(ws + c->ctl_off);
-    GDPSO_HIP(hipMemsetAsync(ctl, 0, sizeof(ChainCtl), stream));
+    static_assert(sizeof(ChainCtl) % 16 == 0, "the control block is cleared in 16-byte words");
+    if (!ctl_cleared) GDPSO_HIP(hipMemsetAsync(ctl, 0, sizeof(ChainCtl), stream));
     const bool timed = g_timing.on && g_timing.used + 2 <= g_timing.events.size();
     const dim3 grid((unsigned)c->grid);
     if (timed) {

@@ -265,11 +265,21 @@ __global__ __launch_bounds__(512) void gen_last_mfma_kernel(const E *__restrict_
 // the two 7-wide windows of a pair span 9 input pixels, read from the zero-padded image
 // in LDS as three wave-wide broadcast 16-byte reads per kernel row (row stride and window
 // start are multiples of 4 floats).  Conv rows of the band stay in LDS for the pooling.
+// The stem is the first kernel of an assessor pass: it also clears the control block of the chained
+// launch that follows later on the same stream (16-byte words, any number of workgroups), which saves
+// that launch a memset of its own.
+__device__ __forceinline__ void stem_zero(f32x4 *__restrict__ zero, int zero_quads, int block, int blocks) {
+    if (zero == nullptr) return;
+    for (int i = block * 512 + (int)threadIdx.x; i < zero_quads; i += blocks * 512) zero[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
 template <typename E>
 __global__ __launch_bounds__(512) void stem_kernel(const float *__restrict__ img01, const float *__restrict__ w,
                                                    const float *__restrict__ scale, const float *__restrict__ shift,
-                                                   int side, int ho, int hp, int band, int ps, E *__restrict__ out) {
+                                                   int side, int ho, int hp, int band, int ps, E *__restrict__ out,
+                                                   f32x4 *__restrict__ zero, int zero_quads) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    stem_zero(zero, zero_quads, (int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
     const int prows = side + 6;
     float *s_img = smem;                // [side+6][ps], zero border of 3 on the left/top
     float *s_conv = smem + prows * ps;  // [(2*band+1)][ho][64]
@@ -347,8 +357,9 @@ template <typename E>
 __global__ __launch_bounds__(512) void stem_mfma_kernel(const float *__restrict__ img01, const float *__restrict__ w,
                                                         const float *__restrict__ scale, const float *__restrict__ shift,
                                                         int side, int ho, int hp, int ps, FastDiv div_ho, FastDiv div_hp,
-                                                        E *__restrict__ out) {
+                                                        E *__restrict__ out, f32x4 *__restrict__ zero, int zero_quads) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    stem_zero(zero, zero_quads, (int)blockIdx.x, (int)gridDim.x);
     const int prows = side + 6, npx = ho * ho, nblk = (npx + 15) / 16;
     // n / d by multiply-shift (FastDiv): the chip has no integer divide
     auto fdiv = [](int v, FastDiv f) { return (int)(((unsigned long long)(unsigned)v * f.mul) >> f.shift); };
@@ -1181,26 +1192,28 @@ static int assessor_forward_impl(const gdpso_assessor *a, void *stream_, int n, 
         const char *e = getenv("GDPSO_STEM_MFMA");
         return e ? e[0] != '0' : true;
     }();
+    const bool use_chain = L.chain != nullptr && single_stream;
+    f32x4 *const ctl_zero = use_chain ? (f32x4 *)(ws + L.chain_ctl) : nullptr;
+    const int ctl_quads = (int)(chain_ctl_bytes() / 16);
     const int mps = (a->side + 6 + 3) / 4 * 4;
     const size_t mfma_smem = ((size_t)(a->side + 6) * mps + (size_t)((a->ho * a->ho + 15) / 16 * 16) * 68) * sizeof(float);
     if (stem_mfma && mfma_smem <= 64 * 1024) {
         GDPSO_WITH_DTYPE(a->dtype, hipLaunchKernelGGL(stem_mfma_kernel<E>, dim3(n), dim3(512), mfma_smem, stream, img01, a->stem_w,
                                                       a->stem_scale, a->stem_shift, a->side, a->ho, a->hp, mps,
-                                                      fast_div_for((unsigned)a->ho), fast_div_for((unsigned)a->hp), (E *)x));
+                                                      fast_div_for((unsigned)a->ho), fast_div_for((unsigned)a->hp), (E *)x, ctl_zero, ctl_quads));
     } else {
         const int rows = 2 * a->stem_band + 1;
         const size_t smem = ((size_t)(a->side + 6) * a->stem_ps + (size_t)rows * a->ho * 64) * sizeof(float);
         dim3 grid(n, ceil_div(a->hp, a->stem_band));
         GDPSO_WITH_DTYPE(a->dtype, hipLaunchKernelGGL(stem_kernel<E>, grid, dim3(512), smem, stream, img01, a->stem_w, a->stem_scale,
-                                                      a->stem_shift, a->side, a->ho, a->hp, a->stem_band, a->stem_ps, (E *)x));
+                                                      a->stem_shift, a->side, a->ho, a->hp, a->stem_band, a->stem_ps, (E *)x, ctl_zero, ctl_quads));
     }
     int rc;
     if ((rc = conv_splitk_prepare(stream, sk))) return rc;
-    const bool use_chain = L.chain != nullptr && single_stream;
     for (size_t bi = 0; bi < L.blocks.size(); ++bi) {
         const Bottleneck &b = L.blocks[bi];
         if (use_chain && (int)bi >= L.chain_first) {
-            if ((int)bi == L.chain_first && (rc = launch_chain(L.chain, stream, workspace))) return rc;
+            if ((int)bi == L.chain_first && (rc = launch_chain(L.chain, stream, workspace, /*ctl_cleared=*/true))) return rc;
             x = ws + L.chain_out;  // (the remaining blocks are all part of the chain)
             continue;
         }
