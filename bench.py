@@ -320,6 +320,27 @@ def main():
                     "executed_frac": round(executed / (ms.value * 1e-3) / 1e12 / peak, 4),
                     # the same launches priced against HBM: algorithmic bytes over kernel time
                     "algorithmic_tb_per_s": round(alg_bytes * launches.value / (ms.value * 1e-3) / 1e12, 3)}
+    # third pass, single process only: where an iteration's time goes.  Generator and assessor are run on
+    # the swarm's positions as calls of their own, back to back without a host synchronisation, with HIP
+    # events between them on the launch stream; the PSO update (personal / global best, move, history) and
+    # the distance diagnostic are what an iteration of the timed loop takes beyond the two.
+    phases = None
+    if rank == 0 and comm is None:
+        n_ph = 20
+        marks = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n_ph)]
+        for it in range(n_ph):
+            marks[it][0].record()
+            img01, _, _ = ev.images(sw.pos)
+            marks[it][1].record()
+            ev.assess(img01, spec)
+            marks[it][2].record()
+        torch.cuda.synchronize(dev)
+        gen_ms = float(np.mean([m[0].elapsed_time(m[1]) for m in marks[2:]]))
+        ass_ms = float(np.mean([m[1].elapsed_time(m[2]) for m in marks[2:]]))
+        phases = {"generator_ms": round(gen_ms, 4), "assessor_ms": round(ass_ms, 4),
+                  "pso_update_and_diagnostic_ms": round(max(0.0, 1e3 * dt / k - gen_ms - ass_ms), 4), "collective_ms": None,
+                  "how": f"HIP events on the launch stream around {n_ph - 2} generator / assessor passes enqueued back to back; "
+                         "the rest = ms_per_step of the timed loop minus the two"}
     if comm is not None:
         comm.dist.barrier()
 
@@ -336,6 +357,7 @@ def main():
             "end_to_end_tflops": round(value * flop_per_eval / 1e12, 3),
             "host_enqueue_ms_per_step": round(1e3 * t_enqueued / k, 4),
             "roofline": roofline,
+            "phases": phases,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(z_dim, n_class, class_index)
