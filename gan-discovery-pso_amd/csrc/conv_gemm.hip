@@ -79,6 +79,7 @@ struct ConvKArgs {
     unsigned phase_word[MAX_PHASES];
     unsigned tiles_n_mul, tiles_n_shift;  // FastDiv by tiles_n
     int per_xcd;                  // workgroups of this layer per XCD (= the last phase's running end)
+    int share_images;             // chains: images per share (the last shares of a batch that does not divide evenly hold fewer, or none)
     int snake;                    // CUs per XCD when the second round of workgroups is dealt in reverse, else 0
 };
 
@@ -457,10 +458,12 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
         }
     }
     const int per_xcd = (int)(sel & 0xffffffu) - base;
-    const int idx = xcd * per_xcd + (slot - base);
-    if (!CHAIN && idx >= 8 * per_xcd - (int)(sel >> 24)) return;  // (a chain's shares hold whole tiles only)
+    // a chain counts a phase's tiles per share (its slot is the tile's index inside the share's rows of the phase)
+    const int idx = CHAIN ? slot - base : xcd * per_xcd + (slot - base);
+    if (!CHAIN && idx >= 8 * per_xcd - (int)(sel >> 24)) return;
     const int tml = fast_div(idx, a.tiles_n_mul, a.tiles_n_shift), tn = idx - tml * a.tiles_n;
-    const int m0 = tml * BM, n0 = tn * BN;
+    int m0 = tml * BM;
+    const int n0 = tn * BN;
     const int sp = CHAIN ? 0 : blockIdx.z;
     // The table is read through the constant address space: that keeps its loads scalar whatever
     // else the kernel does (behind an asm statement or a store the compiler assumes that global
@@ -480,6 +483,14 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
     P.hw_shift = (unsigned)tab[11] & 0xff;
     P.wm_shift = ((unsigned)tab[11] >> 8) & 0xff;
     const int in_y0 = tab[6], in_x0 = tab[7], wstride = tab[8];
+    if constexpr (CHAIN) {
+        // the share's rows of this phase: tiles start at its first row, the last one may be partly (or, in
+        // the last shares of a batch that does not divide by the number of shares, wholly) past its end
+        const int share_rows = a.share_images * P.hm * P.wm;
+        m0 += xcd * share_rows;
+        P.M = min(P.M, (xcd + 1) * share_rows);
+        if (m0 >= P.M) return;
+    }
 #ifdef GDPSO_STAMPS
     asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(wstride), "s"(ntaps) : "memory");  // the phase header has arrived
     GDPSO_STAMP(8)
@@ -1243,8 +1254,10 @@ int conv_splitk_prepare(hipStream_t stream, float *splitk_ws) {
 }
 
 // Fills the kernel arguments of one layer; returns its number of workgroups per split through *tiles.
+// nshare > 0: for a chain over that many shares of the images; a phase's tiles are then counted per share
+// (ceil(images / nshare) images each) and *grid_x is nshare times a share's tiles.
 static int conv_args(const ConvLayer &L, int n_images, const void *in, const void *res, void *out, float *splitk_ws,
-                     ConvKArgs &a, long *grid_x, bool *fused_reduce, int nshare = 8) {
+                     ConvKArgs &a, long *grid_x, bool *fused_reduce, int nshare = 0) {
     if (!dtype_ok(L.dtype)) return fail(GDPSO_ERR_ARG, "conv: unknown element type");
     a.in = in; a.wt = L.wt; a.scale = L.scale; a.shift = L.shift; a.res = res; a.out = out;
     const long tiles_m = m_tiles(L, n_images, L.tile);
@@ -1257,14 +1270,20 @@ static int conv_args(const ConvLayer &L, int n_images, const void *in, const voi
             a.phase_word[p] = 0xffffffu;
             continue;
         }
+        if (nshare > 0) {
+            per_xcd += (long)ceil_div((long)ceil_div(n_images, nshare) * L.phase[p].hm * L.phase[p].wm, tile_bm(L.tile)) * (L.cout / tile_bn(L.tile));
+            a.phase_word[p] = (unsigned)per_xcd;
+            continue;
+        }
         const long tiles = (long)ceil_div((long)n_images * L.phase[p].hm * L.phase[p].wm, tile_bm(L.tile)) * (L.cout / tile_bn(L.tile));
-        const long eighth = ceil_div(tiles, nshare);  // a share's part (an XCD's eighth outside chains)
+        const long eighth = ceil_div(tiles, 8);  // an XCD's part
         per_xcd += eighth;
-        a.phase_word[p] = (unsigned)per_xcd | ((unsigned)(nshare * eighth - tiles) << 24);
+        a.phase_word[p] = (unsigned)per_xcd | ((unsigned)(8 * eighth - tiles) << 24);
     }
     if (per_xcd >= 0xffffff) return fail(GDPSO_ERR_ARG, "conv: too many tiles");
-    *grid_x = nshare * per_xcd;
+    *grid_x = (nshare > 0 ? nshare : 8) * per_xcd;
     a.per_xcd = (int)per_xcd;
+    a.share_images = nshare > 0 ? ceil_div(n_images, nshare) : 0;
     a.snake = (g_snake && L.nphase > 1 && per_xcd > g_cus_per_xcd && per_xcd <= 2 * g_cus_per_xcd) ? g_cus_per_xcd : 0;
     // in-kernel (last-arriver) reduction up to GDPSO_SPLITK_FUSED_MAX splits (default: off); one counter per workgroup index
     *fused_reduce = L.splits > 1 && L.splits <= g_fused_max_splits && (size_t)*grid_x * sizeof(int) <= SPLITK_COUNTER_BYTES;
@@ -1494,25 +1513,16 @@ void chain_free(ConvChain *c) { delete c; }
 int chain_steps(const ConvChain *c) { return c ? (int)c->steps.size() : 0; }
 
 // The tile shape a layer runs with as a step of a chain over `nshare` shares of the images (0: it cannot
-// be a step): one of the three small shapes, and every phase's rows of one share fill whole
-// tiles.  The planner's shape if that holds for it, else the next smaller one; a chain never splits K
-// over workgroups (the planner does when a layer alone has fewer tiles than the device has CUs).
+// be a step): the planner's shape, if it is one of the three small ones.  A share holds
+// ceil(images / nshare) images (the last shares fewer); where its rows of a phase do not fill whole
+// tiles the last tile is partly empty, so a chain wants at least CHAIN_MIN_SHARE_IMAGES images a
+// share: a 1x1 map's 32-row tile is then full.  A chain never splits K over workgroups (the planner
+// does when a layer alone has fewer tiles than the device has CUs).
+constexpr int CHAIN_MIN_SHARE_IMAGES = 32;
 int chain_tile(const ConvLayer &L, int n_images, int nshare) {
-    if (!dtype_ok(L.dtype) || n_images % nshare != 0) return 0;
-    const int kq = dtype_kquant(L.dtype);  // k per wave per K-tile: the K-split tiles need 2 and 4 of them per tap
-    const int order[3] = {64, 32, TILE_32x32};
-    for (int t : order) {
-        // not larger than planned (a layer planned with 128x128 tiles is long enough to stand alone)
-        if (L.tile == 128 || tile_bm(t) > tile_bm(L.tile) || (tile_bm(t) == tile_bm(L.tile) && tile_bn(t) > tile_bn(L.tile))) continue;
-        if (t == 32 && L.cin % (2 * kq) != 0) continue;
-        if (t == TILE_32x32 && L.cin % (4 * kq) != 0) continue;
-        if (L.cout % tile_bn(t) != 0) continue;
-        bool ok = true;
-        for (int p = 0; p < L.nphase && ok; ++p)
-            ok = ((long)(n_images / nshare) * L.phase[p].hm * L.phase[p].wm) % tile_bm(t) == 0;
-        if (ok) return t;
-    }
-    return 0;
+    if (!dtype_ok(L.dtype) || ceil_div(n_images, nshare) < CHAIN_MIN_SHARE_IMAGES) return 0;
+    // (a layer planned with 128x128 tiles is long enough to stand alone)
+    return (L.tile == 64 || L.tile == 32 || L.tile == TILE_32x32) ? L.tile : 0;
 }
 bool chain_layer_ok(const ConvLayer &L, int n_images, int nteams) { return chain_tile(L, n_images, 8 * (nteams == 2 ? 2 : 1)) != 0; }
 
@@ -1521,7 +1531,7 @@ static int chain_gap(const ConvChain &c, const ChainBuf &b, long pixels, int cha
     *gap = 0;
     if (b.bytes == 0) return GDPSO_OK;
     const size_t slice = b.bytes / c.nshare() / 16 * 16;
-    const size_t share_bytes = (size_t)(c.n_images / c.nshare()) * pixels * channels * dtype_size(c.dtype);
+    const size_t share_bytes = (size_t)ceil_div(c.n_images, c.nshare()) * pixels * channels * dtype_size(c.dtype);
     if (slice < share_bytes || slice - share_bytes > 0xffffffffu) return fail(GDPSO_ERR_ARG, "chain: buffer too small for a layer's share");
     *gap = (unsigned)(slice - share_bytes);
     return GDPSO_OK;

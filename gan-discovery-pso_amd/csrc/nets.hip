@@ -862,8 +862,11 @@ std::shared_ptr<const AssLayout> ass_layout(const gdpso_assessor *a, int n) {
     auto Lp = std::make_shared<AssLayout>();
     AssLayout &L = *Lp;
     L.blocks = a->blocks;
-    size_t xy = (size_t)n * a->hp * a->hp * 64, t1 = 0, t2 = 0, sc = 0, sk = 0;
-    auto out_elems = [&](const ConvLayer &c) { return (size_t)n * c.hout * c.wout * c.cout; };
+    // (buffers sized for the batch rounded up to a multiple of 16 images: a chained launch gives each of its 8 or
+    // 16 shares room for ceil(n / shares) images)
+    const size_t n_pad = ((size_t)n + 15) / 16 * 16;
+    size_t xy = n_pad * a->hp * a->hp * 64, t1 = 0, t2 = 0, sc = 0, sk = 0;
+    auto out_elems = [&](const ConvLayer &c) { return n_pad * c.hout * c.wout * c.cout; };
     if (a->kind == 1) {
         xy = (size_t)n * a->alex_h[0] * a->alex_h[0] * a->alex_c1;
         for (int i = 0; i < 3; ++i) {

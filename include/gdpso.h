@@ -359,9 +359,8 @@ int gdpso_chain_debug(int enabled, unsigned drop_xcc_mask, int teams);
 
 /* No counterpart in the reference: the tile shape (64, 32 or 16, as in gdpso_conv_probe) a convolution layer
  * would run with as a step of a chained launch over n_images images with `teams` (1 or 2) teams per XCD, or 0
- * when it cannot be a step (a share of the images does not fill whole tiles in every phase, or the layer alone
- * is planned with 128x128 tiles); negative on a bad argument.  Host only: lets a test check the choice
- * without a GPU. */
+ * when it cannot be a step (fewer than 32 images in a share of the batch, or the layer alone is planned with
+ * 128x128 tiles); negative on a bad argument.  Host only: lets a test check the choice without a GPU. */
 int gdpso_chain_tile_describe(int n_images, int hin, int cin, int cout, int ksize, int stride, int pad, int num_cus, int teams,
                               int dtype);
 

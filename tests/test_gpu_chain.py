@@ -62,9 +62,11 @@ def _logits(eng, lib, synth, model, n, side, chained, drop=0, seed=5, teams=1, d
 
 
 @pytest.mark.parametrize("model,n,side,exact", [("ResNet50", 512, 28, True), ("ResNet50", 256, 28, False), ("ResNet50", 1024, 28, True),
-                                                 ("ResNet101", 512, 28, True), ("ResNet50", 768, 28, False), ("ResNet152", 512, 28, True)])
+                                                 ("ResNet101", 512, 28, True), ("ResNet50", 768, 28, False), ("ResNet152", 512, 28, True),
+                                                 ("ResNet50", 300, 28, False), ("ResNet50", 500, 28, False), ("ResNet50", 1001, 28, False)])
 def test_chain_matches_per_layer_launches(eng, lib, synth, model, n, side, exact):
-    """768 images: 96 a share, so the layers planned with 64-row tiles run with 32-row ones in the chain.
+    """768 images: 96 a share, so the last 64-row tile of a share is half empty; 300, 500, 1001: shares of 38, 63 and
+    126 images, the last share shorter (1001: much shorter), partly filled tiles in most phases.
     exact: the per-layer plan has no split-K layer at this size, so both paths add in the same order (at
     256 images the late stages alone have fewer tiles than the device has CUs and are split; a chain never is)."""
     before = _aborts(lib)

@@ -189,24 +189,22 @@ def test_conv_plan_shapes(pkg):
 
 
 def test_chain_tile_choice(pkg):
-    """Which layers can be steps of the chained launch, and with which tile: every phase's rows of one
-    share of the images (an eighth, a sixteenth with two teams per XCD) must fill whole tiles."""
+    """Which layers can be steps of the chained launch: the planner's tile if it is one of the three small
+    shapes, and at least 32 images in a share of the batch (an eighth, a sixteenth with two teams per XCD)."""
     lib = importlib.import_module("gan-discovery-pso_amd._lib")
     f = lib.lib().gdpso_chain_tile_describe
     F32, BF16 = 0, 1
     assert f(512, 2, 1024, 256, 1, 1, 0, 256, 1, F32) == 16      # stage-3 conv1: the planner's 32x32 tiles
     assert f(512, 4, 128, 512, 1, 1, 0, 256, 1, F32) == 64       # stage-2 conv3: 64x64
-    assert f(512, 4, 128, 128, 3, 1, 1, 256, 1, F32) == 32       # stage-2 conv2: corner phases hold 64 rows a share
-    assert f(512, 7, 256, 128, 1, 1, 0, 256, 2, F32) == 32       # 49 pixels x 32 images: no whole 64-row tiles -> 32x64
-    assert f(512, 1, 2048, 512, 1, 1, 0, 256, 2, F32) == 16      # 32 rows a share
+    assert f(512, 4, 128, 128, 3, 1, 1, 256, 1, F32) == 32       # stage-2 conv2
+    assert f(512, 1, 2048, 512, 1, 1, 0, 256, 2, F32) == 16      # two teams: 32 images a share
     assert f(256, 1, 2048, 512, 1, 1, 0, 256, 1, F32) == 16      # planned with split-K alone; a chain never splits
-    assert f(128, 1, 2048, 512, 1, 1, 0, 256, 1, F32) == 0       # 16 rows a share: no tile fits
-    assert f(500, 2, 1024, 256, 1, 1, 0, 256, 1, F32) == 0       # images do not divide into 8 shares
+    assert f(500, 2, 1024, 256, 1, 1, 0, 256, 1, F32) == 16      # 63 images a share (the last share 59): partly filled tiles
+    assert f(250, 2, 1024, 256, 1, 1, 0, 256, 1, F32) == 16      # 32 images a share
+    assert f(248, 2, 1024, 256, 1, 1, 0, 256, 1, F32) == 0       # 31: too few for a chain to pay
+    assert f(256, 1, 2048, 512, 1, 1, 0, 256, 2, F32) == 0       # ... and 16 with two teams
     assert f(8192, 7, 256, 256, 1, 1, 0, 256, 1, F32) == 0       # long enough for 128x128 tiles: stands alone
-    assert f(512, 2, 1024, 256, 1, 1, 0, 256, 1, BF16) == 16     # 16-bit: K-split tiles need cin in multiples of 256
-    assert f(512, 4, 128, 128, 3, 1, 1, 256, 1, BF16) == 32
-    assert f(512, 2, 64, 64, 1, 1, 0, 256, 1, BF16) == 64        # cin 64 at 16 bit: only the 64x64 tile, which 256 rows a share fill
-    assert f(256, 1, 64, 64, 1, 1, 0, 256, 1, BF16) == 0         # ... and 32 rows a share do not
+    assert f(512, 2, 1024, 256, 1, 1, 0, 256, 1, BF16) == 16
     assert f(512, 2, 1024, 256, 1, 1, 0, 256, 3, F32) < 0
 
 
