@@ -1514,13 +1514,18 @@ int chain_steps(const ConvChain *c) { return c ? (int)c->steps.size() : 0; }
 
 // The tile shape a layer runs with as a step of a chain over `nshare` shares of the images (0: it cannot
 // be a step): the planner's shape, if it is one of the three small ones.  A share holds
-// ceil(images / nshare) images (the last shares fewer); where its rows of a phase do not fill whole
-// tiles the last tile is partly empty, so a chain wants at least CHAIN_MIN_SHARE_IMAGES images a
-// share: a 1x1 map's 32-row tile is then full.  A chain never splits K over workgroups (the planner
-// does when a layer alone has fewer tiles than the device has CUs).
-constexpr int CHAIN_MIN_SHARE_IMAGES = 32;
+// ceil(images / nshare) images (the last shares fewer, or none); where its rows of a phase do not fill
+// whole tiles the last tile is partly empty.  Measured on MI355X, the chain pays at every batch size down
+// to 8 images (one a share: 0.409 ms per swarm iteration against 0.453 with a launch per layer, where
+// the host can barely enqueue the 70 launches as fast as the device runs them), so the threshold
+// (GDPSO_CHAIN_MIN_SHARE, images a share) defaults to 1.  A chain never splits K over workgroups (the
+// planner does when a layer alone has fewer tiles than the device has CUs).
+static int g_chain_min_share_images = [] {
+    const char *e = getenv("GDPSO_CHAIN_MIN_SHARE");
+    return e && atoi(e) > 0 ? atoi(e) : 1;
+}();
 int chain_tile(const ConvLayer &L, int n_images, int nshare) {
-    if (!dtype_ok(L.dtype) || ceil_div(n_images, nshare) < CHAIN_MIN_SHARE_IMAGES) return 0;
+    if (!dtype_ok(L.dtype) || ceil_div(n_images, nshare) < g_chain_min_share_images) return 0;
     // (a layer planned with 128x128 tiles is long enough to stand alone)
     return (L.tile == 64 || L.tile == 32 || L.tile == TILE_32x32) ? L.tile : 0;
 }

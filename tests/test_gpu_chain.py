@@ -63,10 +63,13 @@ def _logits(eng, lib, synth, model, n, side, chained, drop=0, seed=5, teams=1, d
 
 @pytest.mark.parametrize("model,n,side,exact", [("ResNet50", 512, 28, True), ("ResNet50", 256, 28, False), ("ResNet50", 1024, 28, True),
                                                  ("ResNet101", 512, 28, True), ("ResNet50", 768, 28, False), ("ResNet152", 512, 28, True),
-                                                 ("ResNet50", 300, 28, False), ("ResNet50", 500, 28, False), ("ResNet50", 1001, 28, False)])
+                                                 ("ResNet50", 300, 28, False), ("ResNet50", 500, 28, False), ("ResNet50", 1001, 28, False),
+                                                 ("ResNet50", 1, 28, False), ("ResNet50", 5, 28, False), ("ResNet50", 37, 28, False),
+                                                 ("ResNet50", 100, 64, False)])
 def test_chain_matches_per_layer_launches(eng, lib, synth, model, n, side, exact):
     """768 images: 96 a share, so the last 64-row tile of a share is half empty; 300, 500, 1001: shares of 38, 63 and
-    126 images, the last share shorter (1001: much shorter), partly filled tiles in most phases.
+    126 images, the last share shorter (1001: much shorter), partly filled tiles in most phases; 1 and 5 images: most
+    shares empty; 100 images of 64x64: the larger maps.
     exact: the per-layer plan has no split-K layer at this size, so both paths add in the same order (at
     256 images the late stages alone have fewer tiles than the device has CUs and are split; a chain never is)."""
     before = _aborts(lib)
