@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Print the per-kernel timeline of the last complete swarm iteration found in a
-rocprofv3 --kernel-trace CSV, plus per-kernel totals for that iteration.
+"""Print the per-kernel timeline of a complete swarm iteration (generator, assessor AND the PSO step;
+the middle one of those found) in a rocprofv3 --kernel-trace CSV, plus per-kernel totals for it.
 
     python tools/trace_step.py gpurun_out/prof/<host>/<pid>_kernel_trace.csv [--full]
 """
@@ -17,7 +17,13 @@ def main():
     idx = [i for i, r in enumerate(rows) if "latent_prep" in r["Kernel_Name"]]
     if len(idx) < 2:
         raise SystemExit("fewer than two iterations in the trace")
-    s, e = idx[-2], idx[-1]
+    # the stretches between two generator passes that hold a PSO step (the benchmark ends with passes of
+    # generator and assessor alone); of those the middle one, well inside the timed loop
+    whole = [(a, b) for a, b in zip(idx[:-1], idx[1:])
+             if any("swarm_step" in r["Kernel_Name"] or "move_kernel" in r["Kernel_Name"] for r in rows[a:b])]
+    if not whole:
+        raise SystemExit("no complete swarm iteration in the trace")
+    s, e = whole[len(whole) // 2]
     t0 = int(rows[s]["Start_Timestamp"])
     prev_end = None
     tot = defaultdict(lambda: [0, 0.0])
