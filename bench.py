@@ -126,15 +126,20 @@ def dry_run(args, world, rank, result_fd):
     tested where there is no GPU.  The line says "dry_run": true and carries no value."""
     import torch.distributed as dist
     eng = importlib.import_module("gan-discovery-pso_amd.engine")
+    lib = importlib.import_module("gan-discovery-pso_amd._lib")
     if world > 1:
         dist.init_process_group(backend="gloo")
         comm = eng.TorchComm()
         d, p = args.z_dim, 4
-        cand = torch.zeros(world, d + 2, dtype=torch.float64)
+        cand = torch.zeros(world, lib.cand_doubles(d), dtype=torch.float64)
         cand[rank, 0], cand[rank, 1] = 1.0 + rank, rank * p
         pos = torch.full((p, d), float(rank), dtype=torch.float64)
-        allp = comm.all_gather_step(cand, cand[rank], pos, world * p)
+        handle = comm.start_gather_positions(pos, world * p)
+        cand[rank, d + 2] = 10.0 + rank
+        comm.all_gather(cand, cand[rank])
+        allp = handle.wait()
         assert cand[:, 1].tolist() == [float(r * p) for r in range(world)]
+        assert cand[:, d + 2].tolist() == [10.0 + r for r in range(world)]
         assert allp[:, 0].tolist() == [float(r) for r in range(world) for _ in range(p)]
         t = torch.tensor([float(rank)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -18,6 +18,12 @@ ABI_VERSION = 1
 MODE_IN_TRAINING, MODE_OUT_TRAINING = 0, 1
 DTYPES = {"f32": 0, "bf16": 1, "f16": 2}  # GDPSO_DTYPE_*
 CTRL_DOUBLES = 8
+
+
+def cand_doubles(d: int) -> int:
+    """GDPSO_CAND_DOUBLES(d): doubles per candidate record {value, global index, position[d], distance sum}."""
+    return d + 3
+
 CTRL_W, CTRL_GBEST_VAL, CTRL_GBEST_IDX, CTRL_N_IMPROVE, CTRL_STOP_ITER, CTRL_ITERS_DONE = range(6)
 
 c_void_p, c_int, c_size_t, c_double, c_float, c_uint64 = C.c_void_p, C.c_int, C.c_size_t, C.c_double, C.c_float, C.c_uint64
@@ -84,6 +90,10 @@ _PROTOTYPES = {
     "gdpso_swarm_global_best": (c_int, [C.POINTER(SwarmDesc), c_void_p, c_int, c_int, c_int, c_double]),
     "gdpso_swarm_move": (c_int, [C.POINTER(SwarmDesc), c_void_p, c_int, c_double, c_double, c_void_p, c_uint64, c_int]),
     "gdpso_swarm_mean_distance": (c_int, [C.POINTER(SwarmDesc), c_void_p, c_int, c_void_p, c_int]),
+    "gdpso_swarm_distance_part": (c_int, [C.POINTER(SwarmDesc), c_void_p, c_int, c_void_p, c_int, c_int]),
+    "gdpso_swarm_distance_finish": (c_int, [C.POINTER(SwarmDesc), c_void_p, c_int, c_int]),
+    "gdpso_swarm_after_exchange": (c_int, [C.POINTER(SwarmDesc), c_void_p, c_int, c_int, c_int, c_double, c_double, c_double, c_void_p,
+                                           c_uint64, c_int, c_int, c_int]),
     "gdpso_conv_timing_begin": (c_int, [c_int]),
     "gdpso_conv_timing_end": (c_int, [C.POINTER(c_double), C.POINTER(c_int), C.POINTER(c_double)]),
     "gdpso_conv_timing_bytes": (c_double, []),

@@ -38,6 +38,11 @@ __device__ __forceinline__ BestRec wave_best(BestRec r) {
     return r;
 }
 
+// The distance part of a swarm's scratch buffer (the tile sums): behind the personal-best partials, 256-byte aligned.
+__host__ __device__ __forceinline__ double *dist_partials(const gdpso_swarm &s) {
+    return (double *)((char *)s.scratch + ((size_t)((s.n + PB - 1) / PB) * sizeof(BestRec) + 255) / 256 * 256);
+}
+
 __device__ __forceinline__ bool running(const double *ctrl, int iteration) {
     const int stop = (int)ctrl[GDPSO_CTRL_STOP_ITER];
     return stop == 0 || iteration <= stop;
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(256) void candidate_kernel(gdpso_swarm s, int itera
     if ((tid & 63) == 0) s_best[tid >> 6] = r;
     __syncthreads();
     r = better_of(better_of(s_best[0], s_best[1]), better_of(s_best[2], s_best[3]));
-    double *rec = s.cand + (size_t)rank_slot * (s.d + 2);
+    double *rec = s.cand + (size_t)rank_slot * GDPSO_CAND_DOUBLES(s.d);
     const bool have = r.idx != 0x7fffffff && r.val < INFINITY;
     if (tid == 0) {
         rec[0] = have ? (double)r.val : (double)INFINITY;
@@ -137,7 +142,7 @@ __device__ int decide_global_best(const gdpso_swarm &s, int iteration, int sched
     float best = cur;
     int best_slot = -1, best_idx = 0x7fffffff;
     for (int k = 0; k < s.n_ranks; ++k) {
-        const double *rec = s.cand + (size_t)k * (s.d + 2);
+        const double *rec = s.cand + (size_t)k * GDPSO_CAND_DOUBLES(s.d);
         const float v = (float)rec[0];
         const int idx = (int)rec[1];
         if (idx < 0) continue;
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(64) void global_best_kernel(gdpso_swarm s, int iter
     __syncthreads();
     const int slot = s_take;
     if (slot >= 0) {
-        const double *rec = s.cand + (size_t)slot * (s.d + 2);
+        const double *rec = s.cand + (size_t)slot * GDPSO_CAND_DOUBLES(s.d);
         for (int k = tid; k < s.d; k += 64) s.gbest_pos[k] = rec[2 + k];
     }
 }
@@ -295,7 +300,7 @@ __device__ __forceinline__ void small_local_phase(const gdpso_swarm &s, int rank
     __threadfence_block();
     __syncthreads();
     // this swarm's candidate record
-    double *rec = s.cand + (size_t)rank_slot * (s.d + 2);
+    double *rec = s.cand + (size_t)rank_slot * GDPSO_CAND_DOUBLES(s.d);
     const bool have = r.idx != 0x7fffffff && r.val < INFINITY;
     if (tid == 0) {
         rec[0] = have ? (double)r.val : (double)INFINITY;
@@ -378,81 +383,148 @@ __global__ __launch_bounds__(SMALL_THREADS) void swarm_local_small_kernel(gdpso_
     small_local_phase(s, rank_slot, s_better, s_best);
 }
 
-// Swarm.mse (util_pso.py:76-86): mean Euclidean distance over unordered pairs.  Tile of
-// 64 x 64 pairs per workgroup (upper triangle only), float64 throughout; per-workgroup sums
-// are combined in a fixed order by the finishing kernel, so the result is reproducible.
-// DT particles per tile side: a power of two in [8, 64] whose two tiles fit 48 KiB, smaller
-// for small swarms (the tile side fixes the summation order, so it depends on n and d only).
-constexpr int DT_MIN = 8;
-static int dist_tile_side(int d, int n) {
-    int dt = 64;
-    while (dt > DT_MIN && (size_t)2 * dt * d * sizeof(double) > 48 * 1024) dt >>= 1;
-    // small swarms: smaller tiles until there are enough workgroups to spread over the chip
-    while (dt > 16) {
-        const long t = (n + dt - 1) / dt;
-        if (t * (t + 1) / 2 >= 128) break;
-        dt >>= 1;
-    }
-    return dt;
+// Swarm.mse (util_pso.py:76-86): mean Euclidean distance over unordered pairs, float64 throughout.
+// A workgroup of 16 x 16 threads takes a tile of TS x TS pairs (upper triangle of tiles only) and
+// walks the coordinates in chunks of DIST_KC through LDS; a thread holds (TS/16)^2 running sums
+// of squares in registers, so every coordinate read from LDS feeds TS/16 pairs (one pair per two LDS
+// reads made the kernel LDS-bound: 512 us at 4096 particles x 100 coordinates, 43 us this way).
+// Rows are DIST_KC + 2 doubles apart: 16-byte aligned, so two coordinates come with one LDS read, and the
+// 16 lanes that differ in the column read 16 different groups of four banks.  A chunk is always DIST_KC
+// coordinates long (past the last one zeros, which add nothing to a sum of squares), so the loop over it
+// unrolls completely.  Per-tile sums are combined in a fixed order by the finishing kernel, so the result
+// is reproducible.  The tile side depends on n and the number of ranks only (it fixes the summation order).
+// Several ranks: the tiles are dealt round-robin (tile b belongs to part b % n_parts), every rank
+// sums its own, and the sums are added in rank order once they have been exchanged.
+constexpr int DIST_KC = 32, DIST_KCP = DIST_KC + 2;
+static size_t dist_lds_bytes(int ts) { return (size_t)2 * ts * DIST_KCP * sizeof(double); }
+static int dist_tile_side(int n, int n_parts) {
+    // 64: four pairs per LDS read pair, worth it once every part has several tiles per compute unit (a
+    // tile of 64 x 64 pairs x 100 coordinates keeps a compute unit busy for ~15 us, so a launch of fewer
+    // tiles than compute units takes that long however few they are); 32: the same with 1/4 the work
+    // per tile; 16 (one pair per thread, LDS-bound) only for swarms too small to give 32 tiles of 32.
+    auto per_part = [&](int ts) {
+        const long t = (n + ts - 1) / ts;
+        return t * (t + 1) / 2 / n_parts;
+    };
+    if (per_part(64) >= 1024) return 64;
+    if (per_part(32) >= 32) return 32;
+    return 16;
 }
-__device__ __forceinline__ void pair_dist_tile(const double *__restrict__ pos, int n, int d, int DT, int tiles, int block,
-                                                double *__restrict__ partial, double *sd, double *s_sum) {
-    // linear block id -> (ti <= tj) upper-triangular tile
+
+template <int TS>
+__device__ __forceinline__ void pair_dist_tile(const double *__restrict__ pos, int n, int d, int tiles, int block, double *__restrict__ out,
+                                                double *sd, double *s_sum) {
+    constexpr int R = TS / 16;
+    // linear tile id -> (ti <= tj) upper-triangular tile
     int b = block, ti = 0;
     while (b >= tiles - ti) {
         b -= tiles - ti;
         ++ti;
     }
     const int tj = ti + b;
-    const int tid = threadIdx.x;
-    double *si = sd, *sj = sd + DT * d;
-    for (int e = tid; e < DT * d; e += 256) {
-        const int r = e / d;
-        si[e] = (ti * DT + r) < n ? pos[(size_t)ti * DT * d + e] : 0.0;
-        sj[e] = (tj * DT + r) < n ? pos[(size_t)tj * DT * d + e] : 0.0;
-    }
-    __syncthreads();
-    double sum = 0.0;
-    for (int q = tid; q < DT * DT; q += 256) {
-        const int a = q / DT, c = q - a * DT;
-        const int gi = ti * DT + a, gj = tj * DT + c;
-        if (gi < gj && gj < n) {
-            double acc = 0.0;
-            for (int k = 0; k < d; ++k) {
-                const double df = si[a * d + k] - sj[c * d + k];
-                acc += df * df;
-            }
-            sum += sqrt(acc);
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    double *si = sd, *sj = sd + TS * DIST_KCP;
+    double acc[R][R];
+#pragma unroll
+    for (int u = 0; u < R; ++u)
+#pragma unroll
+        for (int v = 0; v < R; ++v) acc[u][v] = 0.0;
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    // a chunk of both tiles travels through registers: requested a chunk ahead, stored once the
+    // previous chunk has been consumed
+    constexpr int EPT = TS * DIST_KC / 256;  // elements per thread and tile
+    double ri[EPT], rj[EPT];
+    auto request = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int e = tid + 256 * q, r = e / DIST_KC, kk = e % DIST_KC;
+            const int gi = ti * TS + r, gj = tj * TS + r;
+            const bool in = k0 + kk < d;
+            ri[q] = in && gi < n ? pos[(size_t)gi * d + k0 + kk] : 0.0;
+            rj[q] = in && gj < n ? pos[(size_t)gj * d + k0 + kk] : 0.0;
+        }
+    };
+    request(0);
+    for (int k0 = 0; k0 < d; k0 += DIST_KC) {
+        if (k0) __syncthreads();  // the previous chunk has been read
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int e = tid + 256 * q, r = e / DIST_KC, kk = e % DIST_KC;
+            si[r * DIST_KCP + kk] = ri[q];
+            sj[r * DIST_KCP + kk] = rj[q];
+        }
+        __syncthreads();
+        if (k0 + DIST_KC < d) request(k0 + DIST_KC);
+#pragma unroll
+        for (int kk = 0; kk < DIST_KC; kk += 2) {
+            f64x2 a[R], c[R];
+#pragma unroll
+            for (int u = 0; u < R; ++u) a[u] = *(const f64x2 *)&si[(ty + 16 * u) * DIST_KCP + kk];
+#pragma unroll
+            for (int v = 0; v < R; ++v) c[v] = *(const f64x2 *)&sj[(tx + 16 * v) * DIST_KCP + kk];
+#pragma unroll
+            for (int u = 0; u < R; ++u)
+#pragma unroll
+                for (int v = 0; v < R; ++v) {
+                    const double d0 = a[u][0] - c[v][0], d1 = a[u][1] - c[v][1];
+                    acc[u][v] = __builtin_fma(d0, d0, acc[u][v]);
+                    acc[u][v] = __builtin_fma(d1, d1, acc[u][v]);
+                }
         }
     }
+    double sum = 0.0;
+#pragma unroll
+    for (int u = 0; u < R; ++u)
+#pragma unroll
+        for (int v = 0; v < R; ++v) {
+            const int gi = ti * TS + ty + 16 * u, gj = tj * TS + tx + 16 * v;
+            if (gi < gj && gj < n) sum += sqrt(acc[u][v]);
+        }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     if ((tid & 63) == 0) s_sum[tid >> 6] = sum;
     __syncthreads();
-    if (tid == 0) partial[block] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+    if (tid == 0) *out = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
 }
 
-__global__ __launch_bounds__(256) void pair_dist_kernel(const double *__restrict__ pos, int n, int d, int DT, int tiles,
+__device__ __forceinline__ void pair_dist_tile_any(int ts, const double *__restrict__ pos, int n, int d, int tiles, int block,
+                                                    double *__restrict__ out, double *sd, double *s_sum) {
+    if (ts == 64)
+        pair_dist_tile<64>(pos, n, d, tiles, block, out, sd, s_sum);
+    else if (ts == 32)
+        pair_dist_tile<32>(pos, n, d, tiles, block, out, sd, s_sum);
+    else
+        pair_dist_tile<16>(pos, n, d, tiles, block, out, sd, s_sum);
+}
+
+// workgroup q of part `part` takes tile part + q * n_parts -> partial[q].  One kernel per tile side: the
+// 64 x 64 tile's 16 running sums per thread cost it 176 registers (two workgroups per compute unit),
+// which the smaller tiles must not inherit.
+template <int TS>
+__global__ __launch_bounds__(256) void pair_dist_kernel(const double *__restrict__ pos, int n, int d, int tiles, int part, int n_parts,
                                                         const double *ctrl, int iteration, double *__restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) double sd[];  // [2][DT][d]
+    __shared__ __attribute__((aligned(16))) double sd[2 * TS * DIST_KCP];
     __shared__ double s_sum[4];
     if (!running(ctrl, iteration)) return;
-    pair_dist_tile(pos, n, d, DT, tiles, blockIdx.x, partial, sd, s_sum);
+    pair_dist_tile<TS>(pos, n, d, tiles, part + (int)blockIdx.x * n_parts, partial + blockIdx.x, sd, s_sum);
 }
 
 // blockIdx.y = swarm of the batch, blockIdx.x = its tile (surplus blocks of smaller swarms exit)
 __global__ __launch_bounds__(256) void pair_dist_multi_kernel(SwarmBatch b, int iteration) {
-    extern __shared__ __attribute__((aligned(16))) double sd[];
+    extern __shared__ __attribute__((aligned(16))) double sd[];  // [2][largest tile side of the batch][DIST_KCP]
     __shared__ double s_sum[4];
     const int k = blockIdx.y;
     const gdpso_swarm &s = b.s[k];
     const int tiles = b.dist_tiles[k];
     if (!s.mean_dist || s.n < 2 || (int)blockIdx.x >= tiles * (tiles + 1) / 2 || !running_multi(s, iteration)) return;
-    pair_dist_tile(s.pos, s.n, s.d, b.dist_tile[k], tiles, blockIdx.x, b.dist_partial[k], sd, s_sum);
+    pair_dist_tile_any(b.dist_tile[k], s.pos, s.n, s.d, tiles, blockIdx.x, b.dist_partial[k] + blockIdx.x, sd, s_sum);
 }
 
-__device__ __forceinline__ void pair_dist_finish(const double *__restrict__ partial, int n_partial, int n, int iteration,
-                                                 double *__restrict__ out, double *s_sum) {
+// The tile sums in a fixed order, in a launch of its own (folded into the tile kernel, with the
+// workgroup that finishes last adding up, it cost more than this launch: every workgroup then pays a
+// device-scope fence); pairs = 0: the sum itself (a rank's share) -> out, else the mean over `pairs` pairs.
+__device__ __forceinline__ void pair_dist_finish(const double *__restrict__ partial, int n_partial, double pairs, double *__restrict__ out,
+                                                 double *s_sum) {
     const int tid = threadIdx.x;
     double sum = 0.0;
     for (int i = tid; i < n_partial; i += 256) sum += partial[i];
@@ -460,14 +532,17 @@ __device__ __forceinline__ void pair_dist_finish(const double *__restrict__ part
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     if ((tid & 63) == 0) s_sum[tid >> 6] = sum;
     __syncthreads();
-    if (tid == 0) out[iteration - 1] = ((s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3])) / (0.5 * (double)n * (double)(n - 1));
+    if (tid == 0) {
+        const double total = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+        *out = pairs == 0.0 ? total : total / pairs;
+    }
 }
 
-__global__ __launch_bounds__(256) void pair_dist_finish_kernel(const double *__restrict__ partial, int n_partial, int n,
+__global__ __launch_bounds__(256) void pair_dist_finish_kernel(const double *__restrict__ partial, int n_partial, double pairs,
                                                                const double *ctrl, int iteration, double *__restrict__ out) {
     __shared__ double s_sum[4];
     if (!running(ctrl, iteration)) return;
-    pair_dist_finish(partial, n_partial, n, iteration, out, s_sum);
+    pair_dist_finish(partial, n_partial, pairs, out, s_sum);
 }
 
 __global__ __launch_bounds__(256) void pair_dist_finish_multi_kernel(SwarmBatch b, int iteration) {
@@ -476,7 +551,46 @@ __global__ __launch_bounds__(256) void pair_dist_finish_multi_kernel(SwarmBatch 
     const gdpso_swarm &s = b.s[k];
     if (!s.mean_dist || s.n < 2 || !running_multi(s, iteration)) return;
     const int tiles = b.dist_tiles[k];
-    pair_dist_finish(b.dist_partial[k], tiles * (tiles + 1) / 2, s.n, iteration, s.mean_dist, s_sum);
+    pair_dist_finish(b.dist_partial[k], tiles * (tiles + 1) / 2, 0.5 * (double)s.n * (double)(s.n - 1), s.mean_dist + (iteration - 1), s_sum);
+}
+
+// The ranks' sums (last slot of every candidate record), added in rank order by one thread -> the
+// mean over `pairs` pairs: the same bits on every rank.
+__device__ __forceinline__ void dist_mean(const gdpso_swarm &s, int iteration, double pairs) {
+    if (!running(s.ctrl, iteration)) return;
+    double total = 0.0;
+    for (int r = 0; r < s.n_ranks; ++r) total += s.cand[(size_t)r * GDPSO_CAND_DOUBLES(s.d) + s.d + 2];
+    s.mean_dist[iteration - 1] = total / pairs;
+}
+
+__global__ void dist_mean_kernel(gdpso_swarm s, int iteration, double pairs) {
+    if (threadIdx.x == 0) dist_mean(s, iteration, pairs);
+}
+
+// What follows the exchange of the candidate records, for a swarm small enough for one workgroup:
+// the mean of the deferred diagnostic (diag_iteration, 0: none), update_global_best and the move.
+__global__ __launch_bounds__(SMALL_THREADS) void swarm_after_exchange_small_kernel(gdpso_swarm s, int iteration, int schedule_inertia,
+                                                                                   int early_stopping, double tolerance, double w_cogn,
+                                                                                   double w_soci, const double *__restrict__ rnd,
+                                                                                   uint64_t seed, int f32_terms, int diag_iteration,
+                                                                                   double pairs) {
+    __shared__ int s_take;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        if (diag_iteration > 0) dist_mean(s, diag_iteration, pairs);
+        s_take = running(s.ctrl, iteration) ? decide_global_best(s, iteration, schedule_inertia, early_stopping, tolerance) : -2;
+    }
+    __syncthreads();
+    if (s_take == -2) return;  // stopped before this iteration
+    if (s_take >= 0) {
+        const double *rec = s.cand + (size_t)s_take * GDPSO_CAND_DOUBLES(s.d);
+        for (int k = tid; k < s.d; k += SMALL_THREADS) s.gbest_pos[k] = rec[2 + k];
+    }
+    __threadfence_block();
+    __syncthreads();
+    const long nd = (long)s.n * s.d;
+    const double w = s.ctrl[GDPSO_CTRL_W];
+    for (long e = tid; e < nd; e += SMALL_THREADS) move_element(s, iteration, e, w, w_cogn, w_soci, rnd, seed, f32_terms);
 }
 
 static int check_swarm(const gdpso_swarm *s) {
@@ -500,8 +614,8 @@ using namespace gdpso;
 extern "C" size_t gdpso_swarm_scratch_bytes(int n) {
     if (n <= 0) return 0;
     const size_t partials = (size_t)ceil_div(n, PB) * sizeof(BestRec);
-    // distance partials sized for the smallest tile side, whatever dim_space turns out to be
-    return (partials + 255) / 256 * 256 + dist_tiles(n, DT_MIN) * sizeof(double) + 256;
+    // distance partials sized for the smallest tile side
+    return (partials + 255) / 256 * 256 + dist_tiles(n, 16) * sizeof(double) + 256;
 }
 
 extern "C" int gdpso_swarm_reset(const gdpso_swarm *s, void *stream, double w_inertia) {
@@ -555,24 +669,79 @@ extern "C" int gdpso_swarm_move(const gdpso_swarm *s, void *stream, int iteratio
     return GDPSO_OK;
 }
 
-extern "C" int gdpso_swarm_mean_distance(const gdpso_swarm *s, void *stream, int iteration, const double *pos_all, int n_all) {
-    int rc = check_swarm(s);
-    if (rc) return rc;
-    GDPSO_REQUIRE(s->mean_dist && pos_all, "swarm_mean_distance: null buffer");
-    GDPSO_REQUIRE(iteration >= 1 && iteration <= s->max_iter, "swarm_mean_distance: iteration out of range");
-    GDPSO_REQUIRE(n_all >= 2, "swarm_mean_distance: needs at least two particles");
-    const int DT = dist_tile_side(s->d, n_all);
-    GDPSO_REQUIRE((size_t)2 * DT * s->d * sizeof(double) <= 64 * 1024, "swarm_mean_distance: dim_space too large");
-    GDPSO_REQUIRE(gdpso_swarm_scratch_bytes(std::max(n_all, s->n)) <= s->scratch_bytes, "swarm_mean_distance: scratch too small");
-    const int tiles = ceil_div(n_all, DT);
-    const int nb = (int)dist_tiles(n_all, DT);
-    double *partial = (double *)((char *)s->scratch + ((size_t)ceil_div(s->n, PB) * sizeof(BestRec) + 255) / 256 * 256);
-    hipLaunchKernelGGL(pair_dist_kernel, dim3(nb), dim3(256), (size_t)2 * DT * s->d * sizeof(double), (hipStream_t)stream, pos_all,
-                       n_all, s->d, DT, tiles, s->ctrl, iteration, partial);
-    hipLaunchKernelGGL(pair_dist_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, nb, n_all, s->ctrl, iteration,
-                       s->mean_dist);
+// tiles of part `part` of `n_parts` -> their sum in *out (pairs == 0) or the mean over `pairs` pairs
+static int launch_distance(const gdpso_swarm *s, void *stream, int iteration, const double *pos_all, int n_all, int part, int n_parts,
+                           double pairs, double *out) {
+    const int ts = dist_tile_side(n_all, n_parts);
+    const int tiles = ceil_div(n_all, ts);
+    const int nb_all = (int)dist_tiles(n_all, ts);
+    const int nb = part < nb_all ? ceil_div(nb_all - part, n_parts) : 0;  // tiles part, part + n_parts, ...
+    double *partial = dist_partials(*s);
+    if (nb > 0) {
+        auto kernel = ts == 64 ? pair_dist_kernel<64> : ts == 32 ? pair_dist_kernel<32> : pair_dist_kernel<16>;
+        hipLaunchKernelGGL(kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, pos_all, n_all, s->d, tiles, part, n_parts, s->ctrl,
+                           iteration, partial);
+    }
+    hipLaunchKernelGGL(pair_dist_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, nb, pairs, s->ctrl, iteration, out);
     GDPSO_HIP(hipGetLastError());
     return GDPSO_OK;
+}
+
+static int check_distance(const gdpso_swarm *s, int iteration, const double *pos_all, int n_all) {
+    int rc = check_swarm(s);
+    if (rc) return rc;
+    GDPSO_REQUIRE(pos_all, "swarm distance: null buffer");
+    GDPSO_REQUIRE(iteration >= 1 && iteration <= s->max_iter, "swarm distance: iteration out of range");
+    GDPSO_REQUIRE(n_all >= 2, "swarm distance: needs at least two particles");
+    GDPSO_REQUIRE(gdpso_swarm_scratch_bytes(std::max(n_all, s->n)) <= s->scratch_bytes, "swarm distance: scratch too small");
+    return GDPSO_OK;
+}
+
+extern "C" int gdpso_swarm_mean_distance(const gdpso_swarm *s, void *stream, int iteration, const double *pos_all, int n_all) {
+    int rc = check_distance(s, iteration, pos_all, n_all);
+    if (rc) return rc;
+    GDPSO_REQUIRE(s->mean_dist, "swarm_mean_distance: the swarm keeps no diagnostic");
+    return launch_distance(s, stream, iteration, pos_all, n_all, 0, 1, 0.5 * (double)n_all * (double)(n_all - 1), s->mean_dist + (iteration - 1));
+}
+
+extern "C" int gdpso_swarm_distance_part(const gdpso_swarm *s, void *stream, int iteration, const double *pos_all, int n_all,
+                                         int rank_slot) {
+    int rc = check_distance(s, iteration, pos_all, n_all);
+    if (rc) return rc;
+    GDPSO_REQUIRE(rank_slot >= 0 && rank_slot < s->n_ranks, "swarm_distance_part: rank_slot out of range");
+    double *slot = s->cand + (size_t)rank_slot * GDPSO_CAND_DOUBLES(s->d) + s->d + 2;
+    return launch_distance(s, stream, iteration, pos_all, n_all, rank_slot, s->n_ranks, 0.0, slot);
+}
+
+extern "C" int gdpso_swarm_distance_finish(const gdpso_swarm *s, void *stream, int iteration, int n_all) {
+    int rc = check_swarm(s);
+    if (rc) return rc;
+    GDPSO_REQUIRE(s->mean_dist, "swarm_distance_finish: the swarm keeps no diagnostic");
+    GDPSO_REQUIRE(iteration >= 1 && iteration <= s->max_iter, "swarm_distance_finish: iteration out of range");
+    GDPSO_REQUIRE(n_all >= 2, "swarm_distance_finish: needs at least two particles");
+    hipLaunchKernelGGL(dist_mean_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, *s, iteration, 0.5 * (double)n_all * (double)(n_all - 1));
+    GDPSO_HIP(hipGetLastError());
+    return GDPSO_OK;
+}
+
+extern "C" int gdpso_swarm_after_exchange(const gdpso_swarm *s, void *stream, int iteration, int schedule_inertia, int early_stopping,
+                                          double tolerance, double w_cogn, double w_soci, const double *rnd, uint64_t seed,
+                                          int f32_first_move, int diag_iteration, int n_all) {
+    int rc = check_swarm(s);
+    if (rc) return rc;
+    GDPSO_REQUIRE(iteration >= 1 && iteration <= s->max_iter, "swarm_after_exchange: iteration out of range");
+    GDPSO_REQUIRE(diag_iteration >= 0 && diag_iteration <= s->max_iter, "swarm_after_exchange: diagnostic iteration out of range");
+    GDPSO_REQUIRE(diag_iteration == 0 || (s->mean_dist && n_all >= 2), "swarm_after_exchange: the diagnostic needs mean_dist and two particles");
+    if (s->n <= SMALL_MAX_N && (long)s->n * s->d <= SMALL_MAX_ELEMS) {
+        hipLaunchKernelGGL(swarm_after_exchange_small_kernel, dim3(1), dim3(SMALL_THREADS), 0, (hipStream_t)stream, *s, iteration,
+                           schedule_inertia, early_stopping, tolerance, w_cogn, w_soci, rnd, seed, (f32_first_move && iteration == 1) ? 1 : 0,
+                           diag_iteration, 0.5 * (double)n_all * (double)(n_all - 1));
+        GDPSO_HIP(hipGetLastError());
+        return GDPSO_OK;
+    }
+    if (diag_iteration > 0 && (rc = gdpso_swarm_distance_finish(s, stream, diag_iteration, n_all))) return rc;
+    if ((rc = gdpso_swarm_global_best(s, stream, iteration, schedule_inertia, early_stopping, tolerance))) return rc;
+    return gdpso_swarm_move(s, stream, iteration, w_cogn, w_soci, rnd, seed, f32_first_move);
 }
 
 extern "C" int gdpso_swarm_iterate(const gdpso_swarm *s, const gdpso_generator *g, const gdpso_assessor *a, const gdpso_run *r,
@@ -656,8 +825,7 @@ extern "C" int gdpso_swarm_iterate_multi(const gdpso_swarm *swarms, const gdpso_
             SwarmBatch b;
             std::memset((void *)&b, 0, sizeof(b));
             bool small = true, dist = false;
-            int max_blocks = 1;
-            size_t lds = 0;
+            int max_blocks = 1, max_ts = 16;
             for (int j = 0; j < cnt; ++j) {
                 const gdpso_swarm &s = swarms[k0 + j];
                 const gdpso_run &r = runs[k0 + j];
@@ -672,13 +840,12 @@ extern "C" int gdpso_swarm_iterate_multi(const gdpso_swarm *swarms, const gdpso_
                 b.f32_terms[j] = 0;
                 small &= s.n <= SMALL_MAX_N && (long)s.n * s.d <= SMALL_MAX_ELEMS;
                 if (r.diagnostics && s.mean_dist && s.n >= 2) {
-                    const int DT = dist_tile_side(s.d, s.n);
-                    GDPSO_REQUIRE((size_t)2 * DT * s.d * sizeof(double) <= 64 * 1024, "swarm_iterate_multi: dim_space too large");
+                    const int DT = dist_tile_side(s.n, 1);
                     b.dist_tile[j] = DT;
                     b.dist_tiles[j] = ceil_div(s.n, DT);
-                    b.dist_partial[j] = (double *)((char *)s.scratch + ((size_t)ceil_div(s.n, PB) * sizeof(BestRec) + 255) / 256 * 256);
+                    b.dist_partial[j] = dist_partials(s);
                     max_blocks = std::max(max_blocks, (int)dist_tiles(s.n, DT));
-                    lds = std::max(lds, (size_t)2 * DT * s.d * sizeof(double));
+                    max_ts = std::max(max_ts, DT);
                     dist = true;
                 } else {
                     b.s[j].mean_dist = nullptr;  // the distance kernels skip this swarm
@@ -697,7 +864,7 @@ extern "C" int gdpso_swarm_iterate_multi(const gdpso_swarm *swarms, const gdpso_
                 }
             }
             if (dist) {
-                hipLaunchKernelGGL(pair_dist_multi_kernel, dim3(max_blocks, cnt), dim3(256), lds, (hipStream_t)stream, b, i);
+                hipLaunchKernelGGL(pair_dist_multi_kernel, dim3(max_blocks, cnt), dim3(256), dist_lds_bytes(max_ts), (hipStream_t)stream, b, i);
                 hipLaunchKernelGGL(pair_dist_finish_multi_kernel, dim3(cnt), dim3(256), 0, (hipStream_t)stream, b, i);
             }
             GDPSO_HIP(hipGetLastError());

@@ -409,7 +409,8 @@ class HipSwarm:
         self.mean_dist = torch.zeros(t, dtype=f64, device=dev) if diagnostics else None
         self.hist_pos = torch.zeros(t + 1, n, d, dtype=f64, device=dev) if history else None
         self.hist_vel = torch.zeros(t + 1, n, d, dtype=f64, device=dev) if history else None
-        self.cand = torch.zeros(self.n_ranks, d + 2, dtype=f64, device=dev)
+        # per rank {value, global index, position[d], sum of the distances of its share of the pairs}
+        self.cand = torch.zeros(self.n_ranks, _lib.cand_doubles(d), dtype=f64, device=dev)
         nscr = max(self.n_global, n) if diagnostics else n
         self.scratch = torch.zeros(_lib.lib().gdpso_swarm_scratch_bytes(nscr), dtype=torch.uint8, device=dev)
         self.fit_hist = torch.zeros(t, n, dtype=f32, device=dev) if record_fitness else None
@@ -468,6 +469,26 @@ class HipSwarm:
     def mean_distance(self, i, pos_all: torch.Tensor):
         with torch.cuda.device(self.device):
             check(_lib.lib().gdpso_swarm_mean_distance(C.byref(self.desc), self._stream(), i, ptr(pos_all), pos_all.shape[0]))
+
+    def distance_part(self, i, pos_all: torch.Tensor):
+        """This rank's share of the diagnostic of iteration i: the distances of every n_ranks-th tile of
+        pairs, summed into the last slot of its candidate record."""
+        with torch.cuda.device(self.device):
+            check(_lib.lib().gdpso_swarm_distance_part(C.byref(self.desc), self._stream(), i, ptr(pos_all), pos_all.shape[0], self.rank))
+
+    def distance_finish(self, i):
+        """The ranks' sums in the exchanged candidate table -> mean_dist[i - 1]."""
+        with torch.cuda.device(self.device):
+            check(_lib.lib().gdpso_swarm_distance_finish(C.byref(self.desc), self._stream(), i, self.n_global))
+
+    def after_exchange(self, i, schedule_inertia, early_stopping, tolerance, w_cogn, w_soci, seed=0, diag_iteration=0):
+        """distance_finish(diag_iteration) (0: none), global_best(i) and move(i) as one call: one launch
+        for swarms that one workgroup can step."""
+        rnd = 0 if self.rand is None else self.rand[i - 1].data_ptr()
+        with torch.cuda.device(self.device):
+            check(_lib.lib().gdpso_swarm_after_exchange(C.byref(self.desc), self._stream(), i, int(schedule_inertia), int(early_stopping),
+                                                        float(tolerance), float(w_cogn), float(w_soci), rnd, int(seed),
+                                                        int(self.f32_first_move), int(diag_iteration), self.n_global))
 
     # -- fused loop (one process)
     def iterate(self, first, count, spec: FitnessSpec, w_cogn, w_soci, schedule_inertia, early_stopping, tolerance,
@@ -619,35 +640,54 @@ def run_loop(swarm, n_iterations, spec, w_cogn, w_soci, *, schedule_inertia=Fals
 
 def sharded_iterations(swarm, comm, first, count, spec, w_cogn, w_soci, schedule_inertia, early_stopping, tolerance,
                        diagnostics, seed=0, poll_every=8, after_phase=None):
-    """Iterations first .. first+count-1 of the sharded loop, ONE exchange per iteration.
+    """Iterations first .. first+count-1 of the sharded loop.  ONE exchange per iteration lies between
+    a rank's fitness values and its move: the all-gather of the candidate records.
 
-    The diagnostic of iteration i (mean pairwise distance of the positions after its move) needs
-    every rank's positions; they are the positions iteration i+1 starts from, so they travel with
-    the candidate records of iteration i+1 (one coalesced launch), and the diagnostic of the last
-    iteration takes one gather of its own at the end.  ``after_phase(i, name)`` is a debugging hook.
+    The diagnostic of iteration i (mean pairwise distance of the positions after its move) needs every
+    rank's positions.  Their all-gather starts right behind the move and runs beside the next
+    iteration's generator and assessor passes (nothing waits for it until those are done); every rank
+    then sums the distances of its share of the pairs into the last slot of its candidate record, the
+    sums travel with the records of iteration i+1, and every rank adds them in rank order.  The last
+    iteration's sums take one more exchange of the records at the end.
+    ``after_phase(i, name)`` is a debugging hook.
     """
     hook = after_phase or (lambda i, name: None)
-    last = 0
+    pending = None  # (iteration, handle of the position all-gather started behind its move)
     for i in range(first, first + count):
         swarm.evaluate(i, spec)
         hook(i, "evaluate")
         swarm.local_best(i)
         hook(i, "local_best")
-        if diagnostics and last:
-            pos_all = comm.all_gather_step(swarm.cand, swarm.cand[swarm.rank], swarm.pos, swarm.n_global)
-            swarm.mean_distance(last, pos_all)
-        else:
-            comm.all_gather(swarm.cand, swarm.cand[swarm.rank])
+        if pending is not None:
+            swarm.distance_part(pending[0], pending[1].wait())
+        comm.all_gather(swarm.cand, swarm.cand[swarm.rank])
         hook(i, "exchange")
-        swarm.global_best(i, schedule_inertia, early_stopping, tolerance)
-        swarm.move(i, w_cogn, w_soci, seed)
+        swarm.after_exchange(i, schedule_inertia, early_stopping, tolerance, w_cogn, w_soci, seed, pending[0] if pending is not None else 0)
+        pending = None
         hook(i, "move")
-        last = i
+        if diagnostics:
+            pending = (i, comm.start_gather_positions(swarm.pos, swarm.n_global))
         if early_stopping and i % poll_every == 0 and int(swarm.control()[_lib.CTRL_STOP_ITER]):
             break
-    if diagnostics and last:
-        swarm.mean_distance(last, comm.gather_positions(swarm.pos, swarm.n_global))
-        hook(last, "distance")
+    if pending is not None:
+        swarm.distance_part(pending[0], pending[1].wait())
+        comm.all_gather(swarm.cand, swarm.cand[swarm.rank])
+        swarm.distance_finish(pending[0])
+        hook(pending[0], "distance")
+
+
+class _Gathered:
+    """Handle of a position all-gather in flight; wait() returns the positions in global particle
+    order (a buffer of the TorchComm that its next position gather overwrites)."""
+
+    def __init__(self, work, result):
+        self._work, self._result = work, result
+
+    def wait(self) -> torch.Tensor:
+        if self._work is not None:
+            self._work.wait()  # device tensors: the CURRENT STREAM waits, not the host
+            self._work = None
+        return self._result() if callable(self._result) else self._result
 
 
 class TorchComm:
@@ -661,29 +701,27 @@ class TorchComm:
         # several ranks on one GPU) device tensors are staged through the host explicitly.  RCCL
         # collectives run in stream order on the device tensors themselves.
         self.host_staged = dist.get_backend(group) == "gloo"
-        # GDPSO_COMM_COALESCE=0 keeps every exchange as two plain all-gathers
-        self.can_coalesce = os.environ.get("GDPSO_COMM_COALESCE", "1") != "0"
-        self.coalesced_steps = 0  # exchanges that went out as one coalesced launch
+        self._row = None
 
-    def _all_gather_flat(self, out_flat: torch.Tensor, inp_flat: torch.Tensor):
+    def _all_gather_flat(self, out_flat: torch.Tensor, inp_flat: torch.Tensor, async_op=False):
         if self.host_staged and out_flat.is_cuda:
             host_in = inp_flat.detach().cpu()  # waits for the producing kernels
             host_out = torch.empty(out_flat.numel(), dtype=out_flat.dtype)
             self.dist.all_gather_into_tensor(host_out, host_in, group=self.group)
             out_flat.copy_(host_out)
-        else:
-            self.dist.all_gather_into_tensor(out_flat, inp_flat, group=self.group)
+            return None
+        return self.dist.all_gather_into_tensor(out_flat, inp_flat, group=self.group, async_op=async_op)
 
     def all_gather(self, out: torch.Tensor, inp: torch.Tensor):
-        # out [W, d+2] is the swarm's candidate table; inp is this rank's row of it
-        self._all_gather_flat(out.view(-1), self._rec_copy(inp).view(-1))
-
-    def _rec_copy(self, inp: torch.Tensor) -> torch.Tensor:
-        # the collective's input is this rank's row of its output: a copy, so that the two never alias
-        if getattr(self, "_rec", None) is None or self._rec.shape != inp.shape or self._rec.device != inp.device:
-            self._rec = torch.empty_like(inp)
-        self._rec.copy_(inp)
-        return self._rec
+        """out [W, ...]: the table of candidate records; inp: this rank's row OF THAT TABLE.  Over RCCL
+        the collective runs in place (its input is the rank's slot of its output, the form the library
+        documents for all-gather), in stream order on the current stream; gloo gets a copy of the row."""
+        if self.host_staged:
+            if self._row is None or self._row.shape != inp.shape or self._row.device != inp.device:
+                self._row = torch.empty_like(inp)
+            self._row.copy_(inp)
+            inp = self._row
+        self._all_gather_flat(out.view(-1), inp.reshape(-1))
 
     def _pos_buffers(self, pos: torch.Tensor, n_global: int):
         n_max = -(-n_global // self.world)
@@ -695,42 +733,31 @@ class TorchComm:
             self._pos_pad = torch.zeros(n_max, d, dtype=pos.dtype, device=pos.device)
         return n_max, self._pos_all
 
-    def all_gather_step(self, cand_out: torch.Tensor, cand_row: torch.Tensor, pos: torch.Tensor, n_global: int) -> torch.Tensor:
-        """The candidate table AND every rank's positions in one exchange: with equal shards the two
-        all-gathers are coalesced into one launch (torch.distributed's coalescing manager, where this
-        torch build has it and the backend accepts it); otherwise they run one after the other, which
-        gives the same tensors.  Returns the positions like gather_positions."""
+    def start_gather_positions(self, pos: torch.Tensor, n_global: int) -> _Gathered:
+        """Begin the all-gather of every rank's positions and return at once.  Over RCCL the collective
+        runs on the backend's own stream behind everything enqueued so far on the current one, so the
+        kernels enqueued next run beside it; ``pos`` must stay as it is until wait() has been called
+        on the handle (the loop's next move comes later than that).  Unequal shards go out as padded
+        blocks and are put in global particle order by wait()."""
         n_max, allp = self._pos_buffers(pos, n_global)
-        staged = self.host_staged and pos.is_cuda
-        if not (staged or n_global != self.world * n_max or not self.can_coalesce):
-            rec = self._rec_copy(cand_row)
-            try:
-                with self.dist._coalescing_manager(group=self.group):
-                    self.dist.all_gather_into_tensor(cand_out.view(-1), rec.view(-1), group=self.group)
-                    self.dist.all_gather_into_tensor(allp.view(-1), pos.reshape(-1), group=self.group)
-                self.coalesced_steps += 1
-                return allp
-            except (AttributeError, NotImplementedError, TypeError, RuntimeError):
-                # no coalescing in this torch build / backend: from now on the plain form (the
-                # failed attempt wrote nothing that the two calls below do not overwrite)
-                self.can_coalesce = False
-        self.all_gather(cand_out, cand_row)
-        return self.gather_positions(pos, n_global)
+        if n_global == self.world * n_max:  # equal shards: gather straight from the swarm state
+            return _Gathered(self._all_gather_flat(allp.view(-1), pos.reshape(-1), async_op=True), allp)
+        self._pos_pad[:pos.shape[0]] = pos
+        work = self._all_gather_flat(allp.view(-1), self._pos_pad.view(-1), async_op=True)
+
+        def assemble():
+            rows = []
+            for r in range(self.world):
+                lo, hi = shard_bounds(n_global, self.world, r)
+                rows.append(allp[r * n_max:r * n_max + (hi - lo)])
+            return torch.cat(rows).contiguous()
+
+        return _Gathered(work, assemble)
 
     def gather_positions(self, pos: torch.Tensor, n_global: int) -> torch.Tensor:
         """Every rank's positions, in global particle order.  The returned tensor is a buffer of
-        this object that the next call overwrites."""
-        n_max, allp = self._pos_buffers(pos, n_global)
-        if n_global == self.world * n_max:  # equal shards: gather straight from the swarm state
-            self._all_gather_flat(allp.view(-1), pos.reshape(-1))
-            return allp
-        self._pos_pad[:pos.shape[0]] = pos
-        self._all_gather_flat(allp.view(-1), self._pos_pad.view(-1))
-        rows = []
-        for r in range(self.world):
-            lo, hi = shard_bounds(n_global, self.world, r)
-            rows.append(allp[r * n_max:r * n_max + (hi - lo)])
-        return torch.cat(rows).contiguous()
+        this object that the next position gather overwrites."""
+        return self.start_gather_positions(pos, n_global).wait()
 
     def gather_rows(self, local: np.ndarray, axis: int, n_global: int) -> np.ndarray:
         """Concatenate per-rank numpy blocks along ``axis`` (end-of-run history collection)."""

@@ -182,12 +182,16 @@ typedef struct {
     double *mean_dist;        /* [max_iter]   mean pairwise distance (util_pso.py:76-86), may be NULL */
     double *hist_pos;         /* [max_iter+1, n, d] particle.history, may be NULL     */
     double *hist_vel;         /* [max_iter+1, n, d] particle.history_vel, may be NULL */
-    double *cand;             /* [n_ranks, d+2] candidate records {val, global idx, pos[d]} */
+    double *cand;             /* [n_ranks, GDPSO_CAND_DOUBLES(d)] records {val, global idx, pos[d], distance sum}:
+                                 what the ranks all-gather once per iteration */
     void *scratch;            /* >= gdpso_swarm_scratch_bytes(n), n = the largest particle count
                                  passed to local_best / mean_distance */
     size_t scratch_bytes;
     int max_iter;
 } gdpso_swarm;
+
+/* doubles per candidate record of a swarm with dim_space d */
+#define GDPSO_CAND_DOUBLES(d) ((d) + 3)
 
 #define GDPSO_CTRL_DOUBLES 8
 #define GDPSO_CTRL_W 0
@@ -227,6 +231,26 @@ int gdpso_swarm_move(const gdpso_swarm *s, void *stream, int iteration, double w
  * `pos_all` [n_all, d] -> s->mean_dist[iteration-1]. */
 int gdpso_swarm_mean_distance(const gdpso_swarm *s, void *stream, int iteration, const double *pos_all,
                               int n_all);
+
+/* The same diagnostic shared between ranks that all hold `pos_all`: the tiles of pairs are dealt
+ * round-robin to the s->n_ranks ranks, `distance_part` leaves the sum of this rank's distances in
+ * the last slot of its own record cand[rank_slot] (so that it travels with the next all-gather of
+ * the records), and once the records have been exchanged `distance_finish` adds the ranks' sums in
+ * rank order and writes the mean to s->mean_dist[iteration-1]: the same value on every rank.  (The
+ * reference's loop is one process, util_pso.py:182; this is its Swarm.mse cut into n_ranks equal
+ * pieces of work.) */
+int gdpso_swarm_distance_part(const gdpso_swarm *s, void *stream, int iteration, const double *pos_all,
+                              int n_all, int rank_slot);
+int gdpso_swarm_distance_finish(const gdpso_swarm *s, void *stream, int iteration, int n_all);
+
+/* Everything a rank does between the exchange of the candidate records and the next iteration, as
+ * one call (one launch for swarms that one workgroup can step): distance_finish(diag_iteration)
+ * when diag_iteration > 0, then swarm_global_best(iteration) and swarm_move(iteration), with the
+ * arguments those take. */
+int gdpso_swarm_after_exchange(const gdpso_swarm *s, void *stream, int iteration, int schedule_inertia,
+                               int early_stopping, double tolerance, double w_cogn, double w_soci,
+                               const double *rand, uint64_t seed, int f32_first_move, int diag_iteration,
+                               int n_all);
 
 /* One whole iteration on one GPU (n_ranks == 1): generator, rescale, assessor, fitness,
  * personal/global best, move, optional diagnostics -- the body of the while loop in

@@ -253,6 +253,16 @@ def mean_pairwise_distance(pos: np.ndarray) -> float:
     return float(np.mean(np.sqrt(np.sum(diff * diff, axis=1))))
 
 
+def pairwise_distance_part(pos: np.ndarray, part: int, n_parts: int) -> float:
+    """Sum of the Euclidean distances of the pairs (i < j) with i % n_parts == part: one of n_parts
+    pieces of the sum behind mean_pairwise_distance (the pieces add up to mean * n (n - 1) / 2)."""
+    n = pos.shape[0]
+    iu = np.triu_indices(n, 1)
+    keep = iu[0] % n_parts == part
+    diff = pos[iu[0][keep]] - pos[iu[1][keep]]
+    return float(np.sum(np.sqrt(np.sum(diff * diff, axis=1))))
+
+
 def run_swarm(fitness, pos, vel, n_iterations, w_inertia, w_cogn, w_soci, *, tolerance=1e-4,
               schedule_inertia=False, early_stopping=True, rand=None, rng=np.random,
               batch: int = 1, record=True, diagnostics=True, f32_first_move=False):

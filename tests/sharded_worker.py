@@ -33,7 +33,7 @@ class NumpySwarm:
         self.vel = vel.copy()
         self.pbest_pos = pos.copy()
         self.pbest_val = np.full(self.n, np.inf, np.float32)
-        self.cand = torch.zeros(n_ranks, self.d + 2, dtype=torch.float64)
+        self.cand = torch.zeros(n_ranks, lib.cand_doubles(self.d), dtype=torch.float64)
         self.ctrl = np.zeros(lib.CTRL_DOUBLES)
         self.ctrl[lib.CTRL_W], self.ctrl[lib.CTRL_GBEST_VAL] = w, np.inf
         self.gbest_pos = np.zeros(self.d)
@@ -52,7 +52,7 @@ class NumpySwarm:
         k = int(np.argmin(self.pbest_val))
         self.cand[self.rank, 0] = float(self.pbest_val[k])
         self.cand[self.rank, 1] = float(self.first_index + k)
-        self.cand[self.rank, 2:] = torch.from_numpy(self.pbest_pos[k])
+        self.cand[self.rank, 2:2 + self.d] = torch.from_numpy(self.pbest_pos[k])
 
     def global_best(self, i, schedule_inertia, early_stopping, tolerance):
         c = self.cand.numpy()
@@ -67,7 +67,7 @@ class NumpySwarm:
             else:
                 self.g_best_val.append(best)
             self.ctrl[lib.CTRL_GBEST_VAL] = best
-            self.gbest_pos = c[slot, 2:].copy()
+            self.gbest_pos = c[slot, 2:2 + self.d].copy()
         self.dummy.append(best)
         if i > 1 and schedule_inertia:
             self.ctrl[lib.CTRL_W] *= 0.99
@@ -81,8 +81,22 @@ class NumpySwarm:
         self.pos = torch.from_numpy(pos + vel)
         self.hist.append(self.pos.numpy().copy())
 
-    def mean_distance(self, i, pos_all):
-        self.mean_mse.append(oracle.mean_pairwise_distance(pos_all.numpy()))
+    def after_exchange(self, i, schedule_inertia, early_stopping, tolerance, w_cogn, w_soci, seed=0, diag_iteration=0):
+        if diag_iteration:
+            self.distance_finish(diag_iteration)
+        self.global_best(i, schedule_inertia, early_stopping, tolerance)
+        self.move(i, w_cogn, w_soci, seed)
+
+    def distance_part(self, i, pos_all):
+        assert pos_all.shape == (self.n_global, self.d)
+        self.cand[self.rank, self.d + 2] = oracle.pairwise_distance_part(pos_all.numpy(), self.rank, self.n_ranks)
+
+    def distance_finish(self, i):
+        assert len(self.mean_mse) == i - 1  # one diagnostic per iteration, in order
+        total = 0.0
+        for r in range(self.n_ranks):
+            total += float(self.cand[r, self.d + 2])
+        self.mean_mse.append(total / (0.5 * self.n_global * (self.n_global - 1)))
 
 
 def main():
@@ -100,7 +114,7 @@ def main():
     hist = comm.gather_rows(np.stack(sw.hist), 1, n)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), hist=hist, dummy=np.array(sw.dummy, np.float32),
              g_best_val=np.array(sw.g_best_val, np.float32), gbest_pos=sw.gbest_pos, mean_mse=np.array(sw.mean_mse),
-             coalesced_steps=np.array(comm.coalesced_steps))
+             )
     dist.destroy_process_group()
 
 

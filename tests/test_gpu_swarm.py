@@ -186,8 +186,9 @@ def test_inverter_variant(mods, synth, name, mode):
 
 
 def test_logical_shards_match_unsharded(mods):
-    """Two shards of one swarm on one device, exchanging candidate records the way the
-    all-gather does, take exactly the decisions of the unsharded swarm."""
+    """Three shards of one swarm on one device, exchanging candidate records the way the all-gather
+    does (the phases in the order of engine.sharded_iterations, the diagnostic one iteration behind),
+    take exactly the decisions of the unsharded swarm."""
     g = load_golden("swarm_n64_t50_z10")
     eng = mods["eng"]
     n, d, iters = int(g["n"]), int(g["d"]), g["fitness"].shape[0]
@@ -200,25 +201,61 @@ def test_logical_shards_match_unsharded(mods):
         eng.HipSwarm.__init__(s, ev, hi - lo, d, int(g["t"]), first_index=lo, n_ranks=3, rank=r, n_global=n)
         s.load(g["pos"][0][lo:hi], g["vel"][0][lo:hi], float(g["w"][0]), rand=g["rand"][:, lo:hi])
         shards.append(s)
+    def exchange():
+        table = torch.stack([s.cand[s.rank] for s in shards])
+        for s in shards:
+            s.cand.copy_(table)
+
+    allpos = None
     for i in range(1, iters + 1):
         for s, (lo, hi) in zip(shards, bounds):
             s.fitness.copy_(torch.from_numpy(g["fitness"][i - 1][lo:hi]))
             s.local_best(i)
-        table = torch.stack([s.cand[s.rank] for s in shards])
-        allpos = None
-        for s in shards:
-            s.cand.copy_(table)
-            s.global_best(i, False, False, 1e-5)
-            s.move(i, float(g["w"][1]), float(g["w"][2]))
+            if i > 1:  # every rank sums the distances of its share of the previous iteration's pairs
+                s.distance_part(i - 1, allpos)
+        exchange()
+        for s in shards:  # the mean of those sums, the global best and the move
+            s.after_exchange(i, False, False, 1e-5, float(g["w"][1]), float(g["w"][2]), diag_iteration=i - 1)
         allpos = torch.cat([s.pos for s in shards])
-        for s in shards:
-            s.mean_distance(i, allpos)
+    for s in shards:
+        s.distance_part(iters, allpos)
+    exchange()
+    for s in shards:
+        s.distance_finish(iters)
     res = [s.results() for s in shards]
     np.testing.assert_array_equal(np.concatenate([r["hist_pos"] for r in res], axis=1), g["pos"])
     for r in res:
         np.testing.assert_array_equal(r["g_best_val"], g["g_best_val"])
         np.testing.assert_array_equal(r["g_best_pos"], g["g_best_pos"])
         np.testing.assert_allclose(r["mean_mse"], g["mean_mse"], rtol=1e-13)
+
+
+@pytest.mark.parametrize("n,d,parts", [(2, 10, 2), (17, 33, 3), (333, 100, 3), (1000, 100, 2), (2100, 7, 8), (4096, 100, 8)])
+def test_distance_diagnostic_sizes(mods, n, d, parts):
+    """Swarm.mse at every tile side (16, 32, 64), with coordinate counts that are and are not multiples
+    of the chunk, tiles past the last particle, and the sizes a weak-scaling run reaches: the whole
+    diagnostic on one rank and the same cut into `parts` shares against float64 on the host."""
+    eng = mods["eng"]
+    ev = type("E", (), {"device": torch.device("cuda:0"), "gen": type("G", (), {"z_dim": d, "side": 28})()})()
+    rs = np.random.RandomState(n + d)
+    pos = torch.from_numpy(rs.standard_normal((n, d)) * rs.uniform(0.1, 3.0, (n, 1))).cuda()
+    want = torch.pdist(pos.cpu()).mean().item()
+    local = max(1, n // parts)
+    swarms = []
+    for r in range(parts):
+        s = object.__new__(eng.HipSwarm)
+        eng.HipSwarm.__init__(s, ev, local, d, 2, first_index=0, n_ranks=parts, rank=r, n_global=n, history=False)
+        s.load(np.zeros((local, d)), np.zeros((local, d)), 0.7)
+        s.distance_part(1, pos)
+        s.mean_distance(2, pos)  # the whole diagnostic on this rank
+        swarms.append(s)
+    table = torch.stack([s.cand[s.rank] for s in swarms])
+    for s in swarms:
+        s.cand.copy_(table)
+        s.distance_finish(1)
+    got = torch.stack([s.mean_dist for s in swarms]).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-13)
+    assert (got[:, 0] == got[0, 0]).all() and (got[:, 1] == got[0, 1]).all()  # every rank, the same bits
 
 
 def test_many_particles_take_the_multi_workgroup_kernels(mods):
@@ -266,8 +303,8 @@ def test_many_particles_take_the_multi_workgroup_kernels(mods):
 
 def test_sharded_loop_over_rccl(mods):
     """engine.sharded_iterations through a real RCCL process group (one rank: all this box has):
-    the coalesced candidate + position exchange, the deferred distance diagnostic and the
-    early stop reproduce the reference trajectory bit for bit."""
+    the position all-gather started behind every move, the distance sums in the next candidate
+    records, the deferred distance diagnostic and the early stop reproduce the reference trajectory bit for bit."""
     import socket
     import torch.distributed as dist
     eng = mods["eng"]

@@ -2,7 +2,8 @@
 
 Checks the host-side protocol of engine.run_loop / engine.TorchComm -- contiguous particle
 shards (uneven for 3 ranks), one all-gather of {value, global index, position} records per
-iteration, the position all-gather of the diagnostic, history collection -- against the
+iteration, the diagnostic's position all-gather started behind every move and its per-rank sums
+riding in the next records, history collection -- against the
 trajectory recorded from the reference.  The device kernels are covered by the GPU tests
 (test_gpu_swarm.py::test_logical_shards_match_unsharded runs the same protocol on HIP)."""
 import os
@@ -15,14 +16,14 @@ import pytest
 from conftest import ROOT, load_golden
 
 
-@pytest.mark.parametrize("world,coalesce", [(2, True), (2, False), (3, True)])
-def test_sharded_loop_matches_reference(tmp_path, world, coalesce):
-    """world 2: equal shards, the per-iteration exchange goes out as ONE coalesced launch (candidate
-    records + positions) or, with coalescing switched off, as two plain all-gathers; world 3: unequal
-    shards (22 + 21 + 21), always the plain form with padded position blocks.  Same results."""
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", GDPSO_COMM_COALESCE="1" if coalesce else "0")
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_loop_matches_reference(tmp_path, world):
+    """One all-gather of the candidate records per iteration (the ranks' distance sums of the previous
+    iteration in their last slot); world 2: equal shards, world 3: unequal shards (22 + 21 + 21),
+    positions gathered as padded blocks."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(29500 + 2 * world + int(coalesce)), os.path.join(ROOT, "tests", "sharded_worker.py"), str(tmp_path)]
+           "--master-port", str(29500 + 2 * world), os.path.join(ROOT, "tests", "sharded_worker.py"), str(tmp_path)]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr[-2000:]
     g = load_golden("swarm_n64_t50_z10")
@@ -32,7 +33,5 @@ def test_sharded_loop_matches_reference(tmp_path, world, coalesce):
         np.testing.assert_array_equal(r["hist"], g["pos"][:iters + 1])          # every rank, whole swarm, bit for bit
         np.testing.assert_array_equal(r["dummy"], g["g_best_val_dummy"][:iters])
         np.testing.assert_allclose(r["mean_mse"], g["mean_mse"][:iters], rtol=1e-12)
-        # every iteration but the first carries the previous move's positions along with its records
-        assert int(r["coalesced_steps"]) == (iters - 1 if (world == 2 and coalesce) else 0)
         n_imp = len(r["g_best_val"])
         np.testing.assert_array_equal(r["g_best_val"], g["g_best_val"][:n_imp])
