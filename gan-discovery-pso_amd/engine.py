@@ -684,7 +684,7 @@ class _Gathered:
         self._work, self._result = work, result
 
     def wait(self) -> torch.Tensor:
-        if self._work is not None:
+        if self._work is not None:  # (None: the collective ran in stream order, or on the host)
             self._work.wait()  # device tensors: the CURRENT STREAM waits, not the host
             self._work = None
         return self._result() if callable(self._result) else self._result
@@ -702,6 +702,11 @@ class TorchComm:
         # collectives run in stream order on the device tensors themselves.
         self.host_staged = dist.get_backend(group) == "gloo"
         self._row = None
+        # Position all-gathers of at least this many bytes (all ranks together) go to the backend's own
+        # stream and run beside the next iteration (two stream hand-shakes: ~25 us of stream time
+        # whatever the size); smaller ones stay on the launch stream like the record exchange
+        # (~8 us plus the transfer itself).
+        self.async_bytes = int(os.environ.get("GDPSO_COMM_ASYNC_BYTES", str(1 << 20)))
 
     def _all_gather_flat(self, out_flat: torch.Tensor, inp_flat: torch.Tensor, async_op=False):
         if self.host_staged and out_flat.is_cuda:
@@ -734,16 +739,17 @@ class TorchComm:
         return n_max, self._pos_all
 
     def start_gather_positions(self, pos: torch.Tensor, n_global: int) -> _Gathered:
-        """Begin the all-gather of every rank's positions and return at once.  Over RCCL the collective
-        runs on the backend's own stream behind everything enqueued so far on the current one, so the
-        kernels enqueued next run beside it; ``pos`` must stay as it is until wait() has been called
-        on the handle (the loop's next move comes later than that).  Unequal shards go out as padded
+        """Begin the all-gather of every rank's positions and return at once.  Over RCCL a large one
+        (async_bytes) runs on the backend's own stream behind everything enqueued so far on the current
+        one, so the kernels enqueued next run beside it; ``pos`` must stay as it is until wait() has been
+        called on the handle (the loop's next move comes later than that).  Unequal shards go out as padded
         blocks and are put in global particle order by wait()."""
         n_max, allp = self._pos_buffers(pos, n_global)
+        beside = allp.numel() * allp.element_size() >= self.async_bytes
         if n_global == self.world * n_max:  # equal shards: gather straight from the swarm state
-            return _Gathered(self._all_gather_flat(allp.view(-1), pos.reshape(-1), async_op=True), allp)
+            return _Gathered(self._all_gather_flat(allp.view(-1), pos.reshape(-1), async_op=beside), allp)
         self._pos_pad[:pos.shape[0]] = pos
-        work = self._all_gather_flat(allp.view(-1), self._pos_pad.view(-1), async_op=True)
+        work = self._all_gather_flat(allp.view(-1), self._pos_pad.view(-1), async_op=beside)
 
         def assemble():
             rows = []

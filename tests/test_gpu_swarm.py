@@ -301,8 +301,11 @@ def test_many_particles_take_the_multi_workgroup_kernels(mods):
     np.testing.assert_array_equal(res["vel"], vel)
 
 
-def test_sharded_loop_over_rccl(mods):
-    """engine.sharded_iterations through a real RCCL process group (one rank: all this box has):
+@pytest.mark.parametrize("beside", [False, True])
+def test_sharded_loop_over_rccl(mods, beside):
+    """engine.sharded_iterations through a real RCCL process group (one rank: all this box has), with
+    the positions' all-gather on the launch stream (small swarms) and on the backend's own stream
+    beside the next iteration (large ones):
     the position all-gather started behind every move, the distance sums in the next candidate
     records, the deferred distance diagnostic and the early stop reproduce the reference trajectory bit for bit."""
     import socket
@@ -325,6 +328,7 @@ def test_sharded_loop_over_rccl(mods):
     try:
         comm = eng.TorchComm()
         assert not comm.host_staged
+        comm.async_bytes = 0 if beside else 1 << 40
         sw = Injected(ev, n, d, t + 1, first_index=0, n_ranks=1, rank=0, n_global=n)
         rand = np.concatenate([g["rand"], np.repeat(g["rand"][-1:], t + 1 - iters, axis=0)])
         sw.load(g["pos"][0], g["vel"][0], float(g["w"][0]), rand=rand)
