@@ -224,8 +224,10 @@ def main():
     p, k, w = args.particles, args.steps, args.warmup
     n_global = p * world
     lo = rank * p
+    # several ranks: equal shards, so the positions travel in the exchange table behind the records
     sw = eng.HipSwarm(ev, p, z_dim, 2 * (w + k), first_index=lo, n_ranks=world, rank=rank, n_global=n_global,
-                      history=True, diagnostics=True)
+                      history=True, diagnostics=True,
+                      table_positions=comm is not None and os.environ.get("GDPSO_BENCH_TABLE_POSITIONS", "1") != "0")
     rs = np.random.RandomState(42)
     r = rs.standard_normal((n_global, 2, z_dim))
     sw.load(r[lo:lo + p, 0], (r[lo:lo + p, 1] - 0.5) / 10, 0.73)

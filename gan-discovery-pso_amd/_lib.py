@@ -21,8 +21,8 @@ CTRL_DOUBLES = 8
 
 
 def cand_doubles(d: int) -> int:
-    """GDPSO_CAND_DOUBLES(d): doubles per candidate record {value, global index, position[d], distance sum}."""
-    return d + 3
+    """GDPSO_CAND_DOUBLES(d): doubles per candidate record {value, global index, position[d], distance sums[2]}."""
+    return d + 4
 
 CTRL_W, CTRL_GBEST_VAL, CTRL_GBEST_IDX, CTRL_N_IMPROVE, CTRL_STOP_ITER, CTRL_ITERS_DONE = range(6)
 
@@ -38,7 +38,7 @@ class SwarmDesc(C.Structure):
         ("fitness", c_void_p), ("gbest_pos", c_void_p), ("ctrl", c_void_p),
         ("g_best_val", c_void_p), ("g_best_val_dummy", c_void_p), ("mean_dist", c_void_p),
         ("hist_pos", c_void_p), ("hist_vel", c_void_p), ("cand", c_void_p),
-        ("scratch", c_void_p), ("scratch_bytes", c_size_t), ("max_iter", c_int),
+        ("scratch", c_void_p), ("scratch_bytes", c_size_t), ("max_iter", c_int), ("cand_stride", c_int),
     ]
 
 
@@ -91,6 +91,7 @@ _PROTOTYPES = {
     "gdpso_swarm_move": (c_int, [C.POINTER(SwarmDesc), c_void_p, c_int, c_double, c_double, c_void_p, c_uint64, c_int]),
     "gdpso_swarm_mean_distance": (c_int, [C.POINTER(SwarmDesc), c_void_p, c_int, c_void_p, c_int]),
     "gdpso_swarm_distance_part": (c_int, [C.POINTER(SwarmDesc), c_void_p, c_int, c_void_p, c_int, c_int]),
+    "gdpso_swarm_distance_part_table": (c_int, [C.POINTER(SwarmDesc), c_void_p, c_int, c_int, c_int]),
     "gdpso_swarm_distance_finish": (c_int, [C.POINTER(SwarmDesc), c_void_p, c_int, c_int]),
     "gdpso_swarm_after_exchange": (c_int, [C.POINTER(SwarmDesc), c_void_p, c_int, c_int, c_int, c_double, c_double, c_double, c_void_p,
                                            c_uint64, c_int, c_int, c_int]),

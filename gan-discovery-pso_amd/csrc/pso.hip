@@ -43,6 +43,14 @@ __host__ __device__ __forceinline__ double *dist_partials(const gdpso_swarm &s) 
     return (double *)((char *)s.scratch + ((size_t)((s.n + PB - 1) / PB) * sizeof(BestRec) + 255) / 256 * 256);
 }
 
+// Record r of the candidate table, and where in a record the distance sum of an iteration lies
+// (two slots, by the iteration's parity: the sums of iteration i are written while those of i - 1 are
+// still being exchanged).
+__host__ __device__ __forceinline__ double *cand_row(const gdpso_swarm &s, int r) {
+    return s.cand + (size_t)r * (s.cand_stride > 0 ? s.cand_stride : GDPSO_CAND_DOUBLES(s.d));
+}
+__host__ __device__ __forceinline__ int dist_slot(int d, int iteration) { return d + 2 + (iteration & 1); }
+
 __device__ __forceinline__ bool running(const double *ctrl, int iteration) {
     const int stop = (int)ctrl[GDPSO_CTRL_STOP_ITER];
     return stop == 0 || iteration <= stop;
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(256) void candidate_kernel(gdpso_swarm s, int itera
     if ((tid & 63) == 0) s_best[tid >> 6] = r;
     __syncthreads();
     r = better_of(better_of(s_best[0], s_best[1]), better_of(s_best[2], s_best[3]));
-    double *rec = s.cand + (size_t)rank_slot * GDPSO_CAND_DOUBLES(s.d);
+    double *rec = cand_row(s, rank_slot);
     const bool have = r.idx != 0x7fffffff && r.val < INFINITY;
     if (tid == 0) {
         rec[0] = have ? (double)r.val : (double)INFINITY;
@@ -142,7 +150,7 @@ __device__ int decide_global_best(const gdpso_swarm &s, int iteration, int sched
     float best = cur;
     int best_slot = -1, best_idx = 0x7fffffff;
     for (int k = 0; k < s.n_ranks; ++k) {
-        const double *rec = s.cand + (size_t)k * GDPSO_CAND_DOUBLES(s.d);
+        const double *rec = cand_row(s, k);
         const float v = (float)rec[0];
         const int idx = (int)rec[1];
         if (idx < 0) continue;
@@ -182,7 +190,7 @@ __global__ __launch_bounds__(64) void global_best_kernel(gdpso_swarm s, int iter
     __syncthreads();
     const int slot = s_take;
     if (slot >= 0) {
-        const double *rec = s.cand + (size_t)slot * GDPSO_CAND_DOUBLES(s.d);
+        const double *rec = cand_row(s, slot);
         for (int k = tid; k < s.d; k += 64) s.gbest_pos[k] = rec[2 + k];
     }
 }
@@ -300,7 +308,7 @@ __device__ __forceinline__ void small_local_phase(const gdpso_swarm &s, int rank
     __threadfence_block();
     __syncthreads();
     // this swarm's candidate record
-    double *rec = s.cand + (size_t)rank_slot * GDPSO_CAND_DOUBLES(s.d);
+    double *rec = cand_row(s, rank_slot);
     const bool have = r.idx != 0x7fffffff && r.val < INFINITY;
     if (tid == 0) {
         rec[0] = have ? (double)r.val : (double)INFINITY;
@@ -411,9 +419,11 @@ static int dist_tile_side(int n, int n_parts) {
     return 16;
 }
 
+// Particle g's coordinates start at pos + (g / blk_rows) * blk_stride + (g % blk_rows) * d: blocks of blk_rows
+// particles, blk_stride doubles apart (one block of n particles for positions that lie back to back).
 template <int TS>
-__device__ __forceinline__ void pair_dist_tile(const double *__restrict__ pos, int n, int d, int tiles, int block, double *__restrict__ out,
-                                                double *sd, double *s_sum) {
+__device__ __forceinline__ void pair_dist_tile(const double *__restrict__ pos, int n, int d, int blk_rows, size_t blk_stride, int tiles,
+                                                int block, double *__restrict__ out, double *sd, double *s_sum) {
     constexpr int R = TS / 16;
     // linear tile id -> (ti <= tj) upper-triangular tile
     int b = block, ti = 0;
@@ -434,14 +444,20 @@ __device__ __forceinline__ void pair_dist_tile(const double *__restrict__ pos, i
     // previous chunk has been consumed
     constexpr int EPT = TS * DIST_KC / 256;  // elements per thread and tile
     double ri[EPT], rj[EPT];
+    const double *pi[EPT], *pj[EPT];  // where this thread's rows of the two tiles start (null: past the last particle)
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int r = (tid + 256 * q) / DIST_KC;
+        const int gi = ti * TS + r, gj = tj * TS + r;
+        pi[q] = gi < n ? pos + (size_t)(gi / blk_rows) * blk_stride + (size_t)(gi % blk_rows) * d : nullptr;
+        pj[q] = gj < n ? pos + (size_t)(gj / blk_rows) * blk_stride + (size_t)(gj % blk_rows) * d : nullptr;
+    }
     auto request = [&](int k0) {
 #pragma unroll
         for (int q = 0; q < EPT; ++q) {
-            const int e = tid + 256 * q, r = e / DIST_KC, kk = e % DIST_KC;
-            const int gi = ti * TS + r, gj = tj * TS + r;
-            const bool in = k0 + kk < d;
-            ri[q] = in && gi < n ? pos[(size_t)gi * d + k0 + kk] : 0.0;
-            rj[q] = in && gj < n ? pos[(size_t)gj * d + k0 + kk] : 0.0;
+            const int k = k0 + (tid + 256 * q) % DIST_KC;
+            ri[q] = k < d && pi[q] ? pi[q][k] : 0.0;
+            rj[q] = k < d && pj[q] ? pj[q][k] : 0.0;
         }
     };
     request(0);
@@ -490,23 +506,24 @@ __device__ __forceinline__ void pair_dist_tile(const double *__restrict__ pos, i
 __device__ __forceinline__ void pair_dist_tile_any(int ts, const double *__restrict__ pos, int n, int d, int tiles, int block,
                                                     double *__restrict__ out, double *sd, double *s_sum) {
     if (ts == 64)
-        pair_dist_tile<64>(pos, n, d, tiles, block, out, sd, s_sum);
+        pair_dist_tile<64>(pos, n, d, n, 0, tiles, block, out, sd, s_sum);
     else if (ts == 32)
-        pair_dist_tile<32>(pos, n, d, tiles, block, out, sd, s_sum);
+        pair_dist_tile<32>(pos, n, d, n, 0, tiles, block, out, sd, s_sum);
     else
-        pair_dist_tile<16>(pos, n, d, tiles, block, out, sd, s_sum);
+        pair_dist_tile<16>(pos, n, d, n, 0, tiles, block, out, sd, s_sum);
 }
 
 // workgroup q of part `part` takes tile part + q * n_parts -> partial[q].  One kernel per tile side: the
 // 64 x 64 tile's 16 running sums per thread cost it 176 registers (two workgroups per compute unit),
 // which the smaller tiles must not inherit.
 template <int TS>
-__global__ __launch_bounds__(256) void pair_dist_kernel(const double *__restrict__ pos, int n, int d, int tiles, int part, int n_parts,
-                                                        const double *ctrl, int iteration, double *__restrict__ partial) {
+__global__ __launch_bounds__(256) void pair_dist_kernel(const double *__restrict__ pos, int n, int d, int blk_rows, size_t blk_stride,
+                                                        int tiles, int part, int n_parts, const double *ctrl, int iteration,
+                                                        double *__restrict__ partial) {
     __shared__ __attribute__((aligned(16))) double sd[2 * TS * DIST_KCP];
     __shared__ double s_sum[4];
     if (!running(ctrl, iteration)) return;
-    pair_dist_tile<TS>(pos, n, d, tiles, part + (int)blockIdx.x * n_parts, partial + blockIdx.x, sd, s_sum);
+    pair_dist_tile<TS>(pos, n, d, blk_rows, blk_stride, tiles, part + (int)blockIdx.x * n_parts, partial + blockIdx.x, sd, s_sum);
 }
 
 // blockIdx.y = swarm of the batch, blockIdx.x = its tile (surplus blocks of smaller swarms exit)
@@ -559,7 +576,7 @@ __global__ __launch_bounds__(256) void pair_dist_finish_multi_kernel(SwarmBatch 
 __device__ __forceinline__ void dist_mean(const gdpso_swarm &s, int iteration, double pairs) {
     if (!running(s.ctrl, iteration)) return;
     double total = 0.0;
-    for (int r = 0; r < s.n_ranks; ++r) total += s.cand[(size_t)r * GDPSO_CAND_DOUBLES(s.d) + s.d + 2];
+    for (int r = 0; r < s.n_ranks; ++r) total += cand_row(s, r)[dist_slot(s.d, iteration)];
     s.mean_dist[iteration - 1] = total / pairs;
 }
 
@@ -583,7 +600,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void swarm_after_exchange_small_kern
     __syncthreads();
     if (s_take == -2) return;  // stopped before this iteration
     if (s_take >= 0) {
-        const double *rec = s.cand + (size_t)s_take * GDPSO_CAND_DOUBLES(s.d);
+        const double *rec = cand_row(s, s_take);
         for (int k = tid; k < s.d; k += SMALL_THREADS) s.gbest_pos[k] = rec[2 + k];
     }
     __threadfence_block();
@@ -596,6 +613,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void swarm_after_exchange_small_kern
 static int check_swarm(const gdpso_swarm *s) {
     GDPSO_REQUIRE(s, "swarm: null descriptor");
     GDPSO_REQUIRE(s->n > 0 && s->d > 0 && s->n_ranks >= 1 && s->max_iter >= 1, "swarm: n, d, n_ranks, max_iter must be positive");
+    GDPSO_REQUIRE(s->cand_stride == 0 || s->cand_stride >= GDPSO_CAND_DOUBLES(s->d), "swarm: cand_stride shorter than a record");
     GDPSO_REQUIRE(s->pos && s->vel && s->pbest_pos && s->pbest_val && s->fitness && s->gbest_pos && s->ctrl && s->g_best_val &&
                       s->g_best_val_dummy && s->cand && s->scratch,
                   "swarm: null state buffer");
@@ -671,7 +689,8 @@ extern "C" int gdpso_swarm_move(const gdpso_swarm *s, void *stream, int iteratio
 
 // tiles of part `part` of `n_parts` -> their sum in *out (pairs == 0) or the mean over `pairs` pairs
 static int launch_distance(const gdpso_swarm *s, void *stream, int iteration, const double *pos_all, int n_all, int part, int n_parts,
-                           double pairs, double *out) {
+                           double pairs, double *out, int blk_rows = 0, size_t blk_stride = 0) {
+    if (blk_rows <= 0) blk_rows = n_all;  // positions back to back
     const int ts = dist_tile_side(n_all, n_parts);
     const int tiles = ceil_div(n_all, ts);
     const int nb_all = (int)dist_tiles(n_all, ts);
@@ -679,8 +698,8 @@ static int launch_distance(const gdpso_swarm *s, void *stream, int iteration, co
     double *partial = dist_partials(*s);
     if (nb > 0) {
         auto kernel = ts == 64 ? pair_dist_kernel<64> : ts == 32 ? pair_dist_kernel<32> : pair_dist_kernel<16>;
-        hipLaunchKernelGGL(kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, pos_all, n_all, s->d, tiles, part, n_parts, s->ctrl,
-                           iteration, partial);
+        hipLaunchKernelGGL(kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, pos_all, n_all, s->d, blk_rows, blk_stride, tiles, part,
+                           n_parts, s->ctrl, iteration, partial);
     }
     hipLaunchKernelGGL(pair_dist_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, nb, pairs, s->ctrl, iteration, out);
     GDPSO_HIP(hipGetLastError());
@@ -709,8 +728,21 @@ extern "C" int gdpso_swarm_distance_part(const gdpso_swarm *s, void *stream, int
     int rc = check_distance(s, iteration, pos_all, n_all);
     if (rc) return rc;
     GDPSO_REQUIRE(rank_slot >= 0 && rank_slot < s->n_ranks, "swarm_distance_part: rank_slot out of range");
-    double *slot = s->cand + (size_t)rank_slot * GDPSO_CAND_DOUBLES(s->d) + s->d + 2;
+    double *slot = cand_row(*s, rank_slot) + dist_slot(s->d, iteration);
     return launch_distance(s, stream, iteration, pos_all, n_all, rank_slot, s->n_ranks, 0.0, slot);
+}
+
+extern "C" int gdpso_swarm_distance_part_table(const gdpso_swarm *s, void *stream, int iteration, int n_all, int rank_slot) {
+    int rc = check_distance(s, iteration, s ? s->cand : nullptr, n_all);
+    if (rc) return rc;
+    GDPSO_REQUIRE(rank_slot >= 0 && rank_slot < s->n_ranks, "swarm_distance_part_table: rank_slot out of range");
+    GDPSO_REQUIRE(n_all % s->n_ranks == 0, "swarm_distance_part_table: the ranks must hold equally many particles");
+    const int blk_rows = n_all / s->n_ranks;
+    GDPSO_REQUIRE((size_t)s->cand_stride >= GDPSO_CAND_DOUBLES(s->d) + (size_t)blk_rows * s->d,
+                  "swarm_distance_part_table: cand_stride leaves no room for a rank's positions behind its record");
+    double *slot = cand_row(*s, rank_slot) + dist_slot(s->d, iteration);
+    return launch_distance(s, stream, iteration, s->cand + GDPSO_CAND_DOUBLES(s->d), n_all, rank_slot, s->n_ranks, 0.0, slot, blk_rows,
+                           (size_t)s->cand_stride);
 }
 
 extern "C" int gdpso_swarm_distance_finish(const gdpso_swarm *s, void *stream, int iteration, int n_all) {

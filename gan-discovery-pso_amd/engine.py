@@ -385,9 +385,11 @@ class HipSwarm:
     and the per-phase kernel launches.  One instance per process / GPU."""
 
     def __init__(self, evaluator: Evaluator, n_local, d, max_iter, *, first_index=0, n_ranks=1, rank=0, n_global=None,
-                 history=True, diagnostics=True, record_fitness=False, pos=None, fitness=None):
+                 history=True, diagnostics=True, record_fitness=False, pos=None, fitness=None, table_positions=False):
         """``pos`` [n, d] float64 / ``fitness`` [n] float32: views into buffers owned by someone else (a
-        HipSwarmBatch lays its swarms' positions and fitness values out back to back)."""
+        HipSwarmBatch lays its swarms' positions and fitness values out back to back).
+        ``table_positions`` (ranks of equal size): this rank's positions live right behind its candidate
+        record in the exchange table, so the one all-gather per iteration moves them too."""
         self.ev, self.device = evaluator, evaluator.device
         self.n, self.d, self.max_iter = int(n_local), int(d), int(max_iter)
         self.first_index, self.n_ranks, self.rank = int(first_index), int(n_ranks), int(rank)
@@ -396,6 +398,18 @@ class HipSwarm:
             raise ValueError(f"dim_space {d} != generator z_dim {evaluator.gen.z_dim}")
         dev, f64, f32 = self.device, torch.float64, torch.float32
         n, t = self.n, self.max_iter
+        # the table the ranks all-gather once per iteration: per rank {value, global index, position[d],
+        # distance sums[2]} and, with table_positions, the rank's particle positions behind that record
+        cd = _lib.cand_doubles(d)
+        self.table_positions = bool(table_positions)
+        if self.table_positions:
+            if pos is not None or self.n_global != n * self.n_ranks:
+                raise ValueError("table_positions needs ranks of equal size and positions owned by the swarm")
+            self.exchange_table = torch.zeros(self.n_ranks, cd + n * d, dtype=f64, device=dev)
+            pos = self.exchange_table[self.rank, cd:].view(n, d)
+        else:
+            self.exchange_table = torch.zeros(self.n_ranks, cd, dtype=f64, device=dev)
+        self.cand = self.exchange_table[:, :cd]
         self.pos = torch.zeros(n, d, dtype=f64, device=dev) if pos is None else pos
         self.vel = torch.zeros(n, d, dtype=f64, device=dev)
         self.pbest_pos = torch.zeros(n, d, dtype=f64, device=dev)
@@ -409,8 +423,6 @@ class HipSwarm:
         self.mean_dist = torch.zeros(t, dtype=f64, device=dev) if diagnostics else None
         self.hist_pos = torch.zeros(t + 1, n, d, dtype=f64, device=dev) if history else None
         self.hist_vel = torch.zeros(t + 1, n, d, dtype=f64, device=dev) if history else None
-        # per rank {value, global index, position[d], sum of the distances of its share of the pairs}
-        self.cand = torch.zeros(self.n_ranks, _lib.cand_doubles(d), dtype=f64, device=dev)
         nscr = max(self.n_global, n) if diagnostics else n
         self.scratch = torch.zeros(_lib.lib().gdpso_swarm_scratch_bytes(nscr), dtype=torch.uint8, device=dev)
         self.fit_hist = torch.zeros(t, n, dtype=f32, device=dev) if record_fitness else None
@@ -423,7 +435,7 @@ class HipSwarm:
             gbest_pos=ptr(self.gbest_pos), ctrl=ptr(self.ctrl), g_best_val=ptr(self.g_best_val),
             g_best_val_dummy=ptr(self.g_best_val_dummy), mean_dist=ptr(self.mean_dist), hist_pos=ptr(self.hist_pos),
             hist_vel=ptr(self.hist_vel), cand=ptr(self.cand), scratch=ptr(self.scratch), scratch_bytes=self.scratch.numel(),
-            max_iter=t)
+            max_iter=t, cand_stride=self.exchange_table.shape[1])
 
     # -- set-up
     def _stream(self):
@@ -472,9 +484,14 @@ class HipSwarm:
 
     def distance_part(self, i, pos_all: torch.Tensor):
         """This rank's share of the diagnostic of iteration i: the distances of every n_ranks-th tile of
-        pairs, summed into the last slot of its candidate record."""
+        pairs, summed into its candidate record (one of two slots, by the iteration's parity)."""
         with torch.cuda.device(self.device):
             check(_lib.lib().gdpso_swarm_distance_part(C.byref(self.desc), self._stream(), i, ptr(pos_all), pos_all.shape[0], self.rank))
+
+    def distance_part_table(self, i):
+        """distance_part on the positions that came with the records (table_positions)."""
+        with torch.cuda.device(self.device):
+            check(_lib.lib().gdpso_swarm_distance_part_table(C.byref(self.desc), self._stream(), i, self.n_global, self.rank))
 
     def distance_finish(self, i):
         """The ranks' sums in the exchanged candidate table -> mean_dist[i - 1]."""
@@ -641,17 +658,49 @@ def run_loop(swarm, n_iterations, spec, w_cogn, w_soci, *, schedule_inertia=Fals
 def sharded_iterations(swarm, comm, first, count, spec, w_cogn, w_soci, schedule_inertia, early_stopping, tolerance,
                        diagnostics, seed=0, poll_every=8, after_phase=None):
     """Iterations first .. first+count-1 of the sharded loop.  ONE exchange per iteration lies between
-    a rank's fitness values and its move: the all-gather of the candidate records.
+    a rank's fitness values and its move: the all-gather of the exchange table (the candidate records).
 
     The diagnostic of iteration i (mean pairwise distance of the positions after its move) needs every
-    rank's positions.  Their all-gather starts right behind the move and runs beside the next
-    iteration's generator and assessor passes (nothing waits for it until those are done); every rank
-    then sums the distances of its share of the pairs into the last slot of its candidate record, the
-    sums travel with the records of iteration i+1, and every rank adds them in rank order.  The last
-    iteration's sums take one more exchange of the records at the end.
+    rank's positions; every rank then sums the distances of its share of the pairs into its candidate
+    record, the sums travel with a later exchange, and every rank adds them in rank order.  Two forms:
+
+    * ``swarm.table_positions`` (ranks of equal size): the positions lie behind the records in the
+      table, so the exchange of iteration i+1 brings them, the sums follow with the exchange of
+      iteration i+2, and there is no other collective; two more exchanges at the end flush the last
+      two diagnostics.
+    * otherwise the positions' all-gather starts right behind the move (large ones beside the next
+      iteration's generator and assessor passes, TorchComm.start_gather_positions), the sums travel
+      with the records of iteration i+1, and one more exchange at the end flushes the last diagnostic.
+
     ``after_phase(i, name)`` is a debugging hook.
     """
     hook = after_phase or (lambda i, name: None)
+    table, row = swarm.exchange_table, swarm.exchange_table[swarm.rank]
+    if diagnostics and getattr(swarm, "table_positions", False):
+        moved = summed = 0  # last iteration whose move is done / whose sums wait in the records for an exchange
+        for i in range(first, first + count):
+            swarm.evaluate(i, spec)
+            hook(i, "evaluate")
+            swarm.local_best(i)
+            hook(i, "local_best")
+            comm.all_gather(table, row)  # records of i, positions after move(moved), sums of `summed`
+            hook(i, "exchange")
+            if moved:
+                swarm.distance_part_table(moved)  # before this rank's own block moves on
+            swarm.after_exchange(i, schedule_inertia, early_stopping, tolerance, w_cogn, w_soci, seed, summed)
+            hook(i, "move")
+            summed, moved = moved, i
+            if early_stopping and i % poll_every == 0 and int(swarm.control()[_lib.CTRL_STOP_ITER]):
+                break
+        if moved:
+            comm.all_gather(table, row)
+            if summed:
+                swarm.distance_finish(summed)
+            swarm.distance_part_table(moved)
+            comm.all_gather(table, row)
+            swarm.distance_finish(moved)
+            hook(moved, "distance")
+        return
     pending = None  # (iteration, handle of the position all-gather started behind its move)
     for i in range(first, first + count):
         swarm.evaluate(i, spec)
@@ -660,7 +709,7 @@ def sharded_iterations(swarm, comm, first, count, spec, w_cogn, w_soci, schedule
         hook(i, "local_best")
         if pending is not None:
             swarm.distance_part(pending[0], pending[1].wait())
-        comm.all_gather(swarm.cand, swarm.cand[swarm.rank])
+        comm.all_gather(table, row)
         hook(i, "exchange")
         swarm.after_exchange(i, schedule_inertia, early_stopping, tolerance, w_cogn, w_soci, seed, pending[0] if pending is not None else 0)
         pending = None
@@ -671,7 +720,7 @@ def sharded_iterations(swarm, comm, first, count, spec, w_cogn, w_soci, schedule
             break
     if pending is not None:
         swarm.distance_part(pending[0], pending[1].wait())
-        comm.all_gather(swarm.cand, swarm.cand[swarm.rank])
+        comm.all_gather(table, row)
         swarm.distance_finish(pending[0])
         hook(pending[0], "distance")
 

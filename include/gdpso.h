@@ -182,16 +182,20 @@ typedef struct {
     double *mean_dist;        /* [max_iter]   mean pairwise distance (util_pso.py:76-86), may be NULL */
     double *hist_pos;         /* [max_iter+1, n, d] particle.history, may be NULL     */
     double *hist_vel;         /* [max_iter+1, n, d] particle.history_vel, may be NULL */
-    double *cand;             /* [n_ranks, GDPSO_CAND_DOUBLES(d)] records {val, global idx, pos[d], distance sum}:
-                                 what the ranks all-gather once per iteration */
+    double *cand;             /* n_ranks records {val, global idx, pos[d], distance sums[2]} of
+                                 GDPSO_CAND_DOUBLES(d) doubles, cand_stride doubles apart: what the
+                                 ranks all-gather once per iteration */
     void *scratch;            /* >= gdpso_swarm_scratch_bytes(n), n = the largest particle count
                                  passed to local_best / mean_distance */
     size_t scratch_bytes;
     int max_iter;
+    int cand_stride;          /* doubles from one record of cand to the next; 0 = GDPSO_CAND_DOUBLES(d).
+                                 Larger when a rank's positions lie behind its record in the same
+                                 table (gdpso_swarm_distance_part_table) */
 } gdpso_swarm;
 
 /* doubles per candidate record of a swarm with dim_space d */
-#define GDPSO_CAND_DOUBLES(d) ((d) + 3)
+#define GDPSO_CAND_DOUBLES(d) ((d) + 4)
 
 #define GDPSO_CTRL_DOUBLES 8
 #define GDPSO_CTRL_W 0
@@ -234,13 +238,20 @@ int gdpso_swarm_mean_distance(const gdpso_swarm *s, void *stream, int iteration,
 
 /* The same diagnostic shared between ranks that all hold `pos_all`: the tiles of pairs are dealt
  * round-robin to the s->n_ranks ranks, `distance_part` leaves the sum of this rank's distances in
- * the last slot of its own record cand[rank_slot] (so that it travels with the next all-gather of
- * the records), and once the records have been exchanged `distance_finish` adds the ranks' sums in
+ * its own record cand[rank_slot] (slot d+2 for even iterations, d+3 for odd ones, so that the sums
+ * of two consecutive iterations can be under way at once) to travel with the next all-gather of
+ * the records, and once the records have been exchanged `distance_finish` adds the ranks' sums in
  * rank order and writes the mean to s->mean_dist[iteration-1]: the same value on every rank.  (The
  * reference's loop is one process, util_pso.py:182; this is its Swarm.mse cut into n_ranks equal
- * pieces of work.) */
+ * pieces of work.)
+ * `distance_part_table` is `distance_part` for the layout in which the positions travel with the
+ * records: rank r's n_all / n_ranks positions lie right behind its record (cand_stride >=
+ * GDPSO_CAND_DOUBLES(d) + n_all / n_ranks * d; s->pos of rank r points at its own block), so one
+ * all-gather of the table moves records and positions together and no second collective is needed. */
 int gdpso_swarm_distance_part(const gdpso_swarm *s, void *stream, int iteration, const double *pos_all,
                               int n_all, int rank_slot);
+int gdpso_swarm_distance_part_table(const gdpso_swarm *s, void *stream, int iteration, int n_all,
+                                    int rank_slot);
 int gdpso_swarm_distance_finish(const gdpso_swarm *s, void *stream, int iteration, int n_all);
 
 /* Everything a rank does between the exchange of the candidate records and the next iteration, as

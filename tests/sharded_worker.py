@@ -25,15 +25,24 @@ lib = importlib.import_module("gan-discovery-pso_amd._lib")
 class NumpySwarm:
     """Same phase methods and attributes as engine.HipSwarm, arithmetic in numpy."""
 
-    def __init__(self, fitness_rows, pos, vel, w, rand, lo, n_global, n_ranks, rank, max_iter):
+    def __init__(self, fitness_rows, pos, vel, w, rand, lo, n_global, n_ranks, rank, max_iter, table_positions=False):
         self.n, self.d = pos.shape
         self.first_index, self.n_ranks, self.rank, self.n_global = lo, n_ranks, rank, n_global
         self.fitness_rows, self.rand = fitness_rows, rand
-        self.pos = torch.from_numpy(pos.copy())
+        cd = lib.cand_doubles(self.d)
+        self.table_positions = table_positions
+        if table_positions:  # this rank's positions behind its record in the exchange table
+            assert n_global == self.n * n_ranks
+            self.exchange_table = torch.zeros(n_ranks, cd + self.n * self.d, dtype=torch.float64)
+            self.pos = self.exchange_table[rank, cd:].view(self.n, self.d)
+            self.pos.copy_(torch.from_numpy(pos))
+        else:
+            self.exchange_table = torch.zeros(n_ranks, cd, dtype=torch.float64)
+            self.pos = torch.from_numpy(pos.copy())
+        self.cand = self.exchange_table[:, :cd]
         self.vel = vel.copy()
         self.pbest_pos = pos.copy()
         self.pbest_val = np.full(self.n, np.inf, np.float32)
-        self.cand = torch.zeros(n_ranks, lib.cand_doubles(self.d), dtype=torch.float64)
         self.ctrl = np.zeros(lib.CTRL_DOUBLES)
         self.ctrl[lib.CTRL_W], self.ctrl[lib.CTRL_GBEST_VAL] = w, np.inf
         self.gbest_pos = np.zeros(self.d)
@@ -78,7 +87,7 @@ class NumpySwarm:
         pos = self.pos.numpy()
         vel = self.ctrl[lib.CTRL_W] * self.vel + (w_soci * r[:, 1:2]) * (self.pbest_pos - pos) + (w_cogn * r[:, 0:1]) * (self.gbest_pos[None] - pos)
         self.vel = vel
-        self.pos = torch.from_numpy(pos + vel)
+        self.pos.copy_(torch.from_numpy(pos + vel))  # in place: the positions may live in the exchange table
         self.hist.append(self.pos.numpy().copy())
 
     def after_exchange(self, i, schedule_inertia, early_stopping, tolerance, w_cogn, w_soci, seed=0, diag_iteration=0):
@@ -89,13 +98,17 @@ class NumpySwarm:
 
     def distance_part(self, i, pos_all):
         assert pos_all.shape == (self.n_global, self.d)
-        self.cand[self.rank, self.d + 2] = oracle.pairwise_distance_part(pos_all.numpy(), self.rank, self.n_ranks)
+        self.cand[self.rank, self.d + 2 + (i & 1)] = oracle.pairwise_distance_part(pos_all.numpy(), self.rank, self.n_ranks)
+
+    def distance_part_table(self, i):
+        cd = lib.cand_doubles(self.d)
+        self.distance_part(i, self.exchange_table[:, cd:].reshape(self.n_global, self.d))
 
     def distance_finish(self, i):
         assert len(self.mean_mse) == i - 1  # one diagnostic per iteration, in order
         total = 0.0
         for r in range(self.n_ranks):
-            total += float(self.cand[r, self.d + 2])
+            total += float(self.cand[r, self.d + 2 + (i & 1)])
         self.mean_mse.append(total / (0.5 * self.n_global * (self.n_global - 1)))
 
 
@@ -106,8 +119,9 @@ def main():
     g = np.load(os.path.join(ROOT, "tests", "golden", "swarm_n64_t50_z10.npz"))
     n, iters = int(g["n"]), 12
     lo, hi = eng.shard_bounds(n, world, rank)
+    table = os.environ.get("GDPSO_TEST_TABLE_POSITIONS") == "1"
     sw = NumpySwarm(g["fitness"][:iters, lo:hi], g["pos"][0][lo:hi], g["vel"][0][lo:hi], float(g["w"][0]),
-                    g["rand"][:iters, lo:hi], lo, n, world, rank, iters)
+                    g["rand"][:iters, lo:hi], lo, n, world, rank, iters, table_positions=table)
     comm = eng.TorchComm()
     eng.run_loop(sw, iters, None, float(g["w"][1]), float(g["w"][2]), schedule_inertia=False, early_stopping=False,
                  tolerance=1e-5, diagnostics=True, comm=comm)

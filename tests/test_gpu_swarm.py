@@ -185,49 +185,76 @@ def test_inverter_variant(mods, synth, name, mode):
     np.testing.assert_allclose(np.concatenate(sw.g_best_val), g["g_best_val"], atol=TOL)
 
 
-def test_logical_shards_match_unsharded(mods):
-    """Three shards of one swarm on one device, exchanging candidate records the way the all-gather
-    does (the phases in the order of engine.sharded_iterations, the diagnostic one iteration behind),
+@pytest.mark.parametrize("n_shards,table", [(3, False), (2, False), (2, True), (4, True)])
+def test_logical_shards_match_unsharded(mods, n_shards, table):
+    """Shards of one swarm on one device, exchanging their tables the way the in-place all-gather does
+    (the phases in the order of engine.sharded_iterations: positions gathered behind every move and the
+    diagnostic one exchange behind, or positions in the exchange table and the diagnostic two behind),
     take exactly the decisions of the unsharded swarm."""
     g = load_golden("swarm_n64_t50_z10")
     eng = mods["eng"]
     n, d, iters = int(g["n"]), int(g["d"]), g["fitness"].shape[0]
     ev = type("E", (), {"device": torch.device("cuda:0"), "gen": type("G", (), {"z_dim": d, "side": 28})()})()
-    bounds = [eng.shard_bounds(n, 3, r) for r in range(3)]
-    assert bounds[0][0] == 0 and bounds[-1][1] == n and all(b[1] - b[0] in (21, 22) for b in bounds)
+    bounds = [eng.shard_bounds(n, n_shards, r) for r in range(n_shards)]
+    assert bounds[0][0] == 0 and bounds[-1][1] == n
     shards = []
     for r, (lo, hi) in enumerate(bounds):
         s = object.__new__(eng.HipSwarm)
-        eng.HipSwarm.__init__(s, ev, hi - lo, d, int(g["t"]), first_index=lo, n_ranks=3, rank=r, n_global=n)
+        eng.HipSwarm.__init__(s, ev, hi - lo, d, int(g["t"]), first_index=lo, n_ranks=n_shards, rank=r, n_global=n, table_positions=table)
         s.load(g["pos"][0][lo:hi], g["vel"][0][lo:hi], float(g["w"][0]), rand=g["rand"][:, lo:hi])
         shards.append(s)
-    def exchange():
-        table = torch.stack([s.cand[s.rank] for s in shards])
-        for s in shards:
-            s.cand.copy_(table)
+    wc, ws_ = float(g["w"][1]), float(g["w"][2])
 
-    allpos = None
-    for i in range(1, iters + 1):
+    def exchange():  # every rank's own row to everybody
+        rows = [s.exchange_table[s.rank].clone() for s in shards]
+        for s in shards:
+            for r, row in enumerate(rows):
+                if r != s.rank:
+                    s.exchange_table[r].copy_(row)
+
+    def fitness(i):
         for s, (lo, hi) in zip(shards, bounds):
             s.fitness.copy_(torch.from_numpy(g["fitness"][i - 1][lo:hi]))
             s.local_best(i)
-            if i > 1:  # every rank sums the distances of its share of the previous iteration's pairs
-                s.distance_part(i - 1, allpos)
+
+    if table:
+        for i in range(1, iters + 1):
+            fitness(i)
+            exchange()
+            for s in shards:
+                if i > 1:
+                    s.distance_part_table(i - 1)
+                s.after_exchange(i, False, False, 1e-5, wc, ws_, diag_iteration=max(0, i - 2))
         exchange()
-        for s in shards:  # the mean of those sums, the global best and the move
-            s.after_exchange(i, False, False, 1e-5, float(g["w"][1]), float(g["w"][2]), diag_iteration=i - 1)
-        allpos = torch.cat([s.pos for s in shards])
-    for s in shards:
-        s.distance_part(iters, allpos)
-    exchange()
-    for s in shards:
-        s.distance_finish(iters)
+        for s in shards:
+            s.distance_finish(iters - 1)
+            s.distance_part_table(iters)
+        exchange()
+        for s in shards:
+            s.distance_finish(iters)
+    else:
+        allpos = None
+        for i in range(1, iters + 1):
+            fitness(i)
+            if i > 1:
+                for s in shards:
+                    s.distance_part(i - 1, allpos)
+            exchange()
+            for s in shards:
+                s.after_exchange(i, False, False, 1e-5, wc, ws_, diag_iteration=i - 1)
+            allpos = torch.cat([s.pos for s in shards])
+        for s in shards:
+            s.distance_part(iters, allpos)
+        exchange()
+        for s in shards:
+            s.distance_finish(iters)
     res = [s.results() for s in shards]
     np.testing.assert_array_equal(np.concatenate([r["hist_pos"] for r in res], axis=1), g["pos"])
     for r in res:
         np.testing.assert_array_equal(r["g_best_val"], g["g_best_val"])
         np.testing.assert_array_equal(r["g_best_pos"], g["g_best_pos"])
         np.testing.assert_allclose(r["mean_mse"], g["mean_mse"], rtol=1e-13)
+        np.testing.assert_array_equal(r["mean_mse"], res[0]["mean_mse"])  # every rank, the same bits
 
 
 @pytest.mark.parametrize("n,d,parts", [(2, 10, 2), (17, 33, 3), (333, 100, 3), (1000, 100, 2), (2100, 7, 8), (4096, 100, 8)])
@@ -253,6 +280,19 @@ def test_distance_diagnostic_sizes(mods, n, d, parts):
     for s in swarms:
         s.cand.copy_(table)
         s.distance_finish(1)
+    if n % parts == 0:  # the same once more with the positions read from the exchange table
+        tabled = []
+        for r in range(parts):
+            s = object.__new__(eng.HipSwarm)
+            eng.HipSwarm.__init__(s, ev, n // parts, d, 2, first_index=0, n_ranks=parts, rank=r, n_global=n, history=False,
+                                  table_positions=True)
+            s.load(np.zeros((n // parts, d)), np.zeros((n // parts, d)), 0.7)
+            cd = s.cand.shape[1]
+            s.exchange_table[:, cd:].copy_(pos.view(parts, -1))
+            s.distance_part_table(1)
+            tabled.append(s)
+        for r, s in enumerate(tabled):
+            assert s.cand[r, d + 3].item() == swarms[r].cand[r, d + 3].item()  # iteration 1: the odd slot
     got = torch.stack([s.mean_dist for s in swarms]).cpu().numpy()
     np.testing.assert_allclose(got, want, rtol=1e-13)
     assert (got[:, 0] == got[0, 0]).all() and (got[:, 1] == got[0, 1]).all()  # every rank, the same bits
@@ -301,11 +341,11 @@ def test_many_particles_take_the_multi_workgroup_kernels(mods):
     np.testing.assert_array_equal(res["vel"], vel)
 
 
-@pytest.mark.parametrize("beside", [False, True])
-def test_sharded_loop_over_rccl(mods, beside):
+@pytest.mark.parametrize("beside,table", [(False, False), (True, False), (False, True)])
+def test_sharded_loop_over_rccl(mods, beside, table):
     """engine.sharded_iterations through a real RCCL process group (one rank: all this box has), with
-    the positions' all-gather on the launch stream (small swarms) and on the backend's own stream
-    beside the next iteration (large ones):
+    the positions' all-gather on the launch stream (small swarms), on the backend's own stream beside
+    the next iteration (large ones), or the positions in the exchange table (no gather of their own):
     the position all-gather started behind every move, the distance sums in the next candidate
     records, the deferred distance diagnostic and the early stop reproduce the reference trajectory bit for bit."""
     import socket
@@ -329,7 +369,7 @@ def test_sharded_loop_over_rccl(mods, beside):
         comm = eng.TorchComm()
         assert not comm.host_staged
         comm.async_bytes = 0 if beside else 1 << 40
-        sw = Injected(ev, n, d, t + 1, first_index=0, n_ranks=1, rank=0, n_global=n)
+        sw = Injected(ev, n, d, t + 1, first_index=0, n_ranks=1, rank=0, n_global=n, table_positions=table)
         rand = np.concatenate([g["rand"], np.repeat(g["rand"][-1:], t + 1 - iters, axis=0)])
         sw.load(g["pos"][0], g["vel"][0], float(g["w"][0]), rand=rand)
         # two calls, as bench.py makes them (warm-up, then the timed steps): the diagnostic of the
