@@ -341,6 +341,83 @@ def test_many_particles_take_the_multi_workgroup_kernels(mods):
     np.testing.assert_array_equal(res["vel"], vel)
 
 
+@pytest.mark.parametrize("table", [False, True])
+def test_sharded_large_swarm(mods, table):
+    """Two logical ranks of 2600 particles each (too many for the one-workgroup kernels: after_exchange
+    falls back to distance_finish + global_best + move, the distance tiles are 64 x 64 and, with the
+    positions in the exchange table, cross the boundary between the ranks' blocks) against numpy
+    float64 on the same fitness values and r1/r2."""
+    eng = mods["eng"]
+    n_loc, ranks, d, iters = 2600, 2, 10, 4
+    n = n_loc * ranks
+    rs = np.random.RandomState(23)
+    pos, vel = rs.standard_normal((n, d)), rs.standard_normal((n, d)) * 0.1
+    fit = rs.random_sample((iters, n)).astype(np.float32)
+    fit[2, 17] = fit[2, 3000] = np.float32(-1.0)  # a tie between the two ranks: the lower index wins
+    rand = rs.random_sample((iters, n, 2))
+    w, wc, ws_ = 0.73, 1.496, 1.3
+    ev = type("E", (), {"device": torch.device("cuda:0"), "gen": type("G", (), {"z_dim": d, "side": 28})()})()
+    shards = []
+    for r in range(ranks):
+        s = object.__new__(eng.HipSwarm)
+        eng.HipSwarm.__init__(s, ev, n_loc, d, iters, first_index=r * n_loc, n_ranks=ranks, rank=r, n_global=n, history=False,
+                              table_positions=table)
+        s.load(pos[r * n_loc:(r + 1) * n_loc], vel[r * n_loc:(r + 1) * n_loc], w, rand=rand[:, r * n_loc:(r + 1) * n_loc])
+        shards.append(s)
+
+    def exchange():
+        rows = [s.exchange_table[s.rank].clone() for s in shards]
+        for s in shards:
+            for r, row in enumerate(rows):
+                if r != s.rank:
+                    s.exchange_table[r].copy_(row)
+
+    pb_val, pb_pos = np.full(n, np.inf, np.float32), pos.copy()
+    g_val, g_pos = np.float32(np.inf), np.zeros(d)
+    want_dist, allpos = [], None
+    for i in range(1, iters + 1):
+        for r, s in enumerate(shards):
+            s.fitness.copy_(torch.from_numpy(fit[i - 1][r * n_loc:(r + 1) * n_loc]))
+            s.local_best(i)
+            if not table and i > 1:
+                s.distance_part(i - 1, allpos)
+        exchange()
+        for s in shards:
+            if table and i > 1:
+                s.distance_part_table(i - 1)
+            s.after_exchange(i, False, False, 1e-5, wc, ws_, diag_iteration=max(0, i - 2) if table else i - 1)
+        allpos = torch.cat([s.pos for s in shards])
+        better = fit[i - 1] < pb_val
+        pb_val = np.where(better, fit[i - 1], pb_val)
+        pb_pos = np.where(better[:, None], pos, pb_pos)
+        k = int(np.argmin(pb_val))
+        if pb_val[k] < g_val:
+            g_val, g_pos = pb_val[k], pb_pos[k].copy()
+        r1, r2 = rand[i - 1][:, 0:1], rand[i - 1][:, 1:2]
+        vel = (w * vel + (ws_ * r2) * (pb_pos - pos)) + (wc * r1) * (g_pos[None] - pos)
+        pos = pos + vel
+        want_dist.append(torch.pdist(torch.from_numpy(pos)).mean().item())
+    if table:
+        exchange()
+        for s in shards:
+            s.distance_finish(iters - 1)
+            s.distance_part_table(iters)
+    else:
+        for s in shards:
+            s.distance_part(iters, allpos)
+    exchange()
+    for s in shards:
+        s.distance_finish(iters)
+    res = [s.results() for s in shards]
+    np.testing.assert_array_equal(np.concatenate([r["pos"] for r in res]), pos)
+    np.testing.assert_array_equal(np.concatenate([r["vel"] for r in res]), vel)
+    for r in res:
+        assert r["gbest_val"] == g_val and r["gbest_idx"] == 17
+        np.testing.assert_array_equal(r["g_best_pos"], g_pos)
+        np.testing.assert_allclose(r["mean_mse"], want_dist, rtol=1e-13)
+        np.testing.assert_array_equal(r["mean_mse"], res[0]["mean_mse"])
+
+
 @pytest.mark.parametrize("beside,table", [(False, False), (True, False), (False, True)])
 def test_sharded_loop_over_rccl(mods, beside, table):
     """engine.sharded_iterations through a real RCCL process group (one rank: all this box has), with
