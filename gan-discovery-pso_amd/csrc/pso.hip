@@ -13,7 +13,9 @@
 
 namespace gdpso {
 
-constexpr int PB = 256;  // particles per workgroup in the personal-best kernel
+// particles per workgroup in the personal-best kernel: few, because a workgroup also copies the improved
+// particles' positions (PB x d doubles) and at 512 particles x 100 dimensions two workgroups of 256 took 16.7 us
+constexpr int PB = 32;
 
 struct BestRec {
     float val;
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void pbest_kernel(gdpso_swarm s, int iteration
     r.val = INFINITY;
     r.idx = 0x7fffffff;
     bool better = false;
-    if (p < s.n) {
+    if (tid < PB && p < s.n) {
         const float f = s.fitness[p];
         float pb = s.pbest_val[p];
         better = f < pb;
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256) void pbest_kernel(gdpso_swarm s, int iteration
         r.val = pb;
         r.idx = s.first_index + p;
     }
-    s_better[tid] = better;
+    if (tid < PB) s_better[tid] = better;
     r = wave_best(r);
     if ((tid & 63) == 0) s_best[tid >> 6] = r;
     __syncthreads();
@@ -117,11 +119,9 @@ __global__ __launch_bounds__(256) void pbest_kernel(gdpso_swarm s, int iteration
 }
 
 // Reduces the per-workgroup partials to this rank's candidate record
-// {value, global index, personal-best position}.
-__global__ __launch_bounds__(256) void candidate_kernel(gdpso_swarm s, int iteration, const BestRec *__restrict__ partial,
-                                                        int n_partial, int rank_slot) {
-    __shared__ BestRec s_best[4];
-    if (!running(s.ctrl, iteration)) return;
+// {value, global index, personal-best position} (every thread of a 256-thread workgroup calls it).
+__device__ __forceinline__ void write_candidate(const gdpso_swarm &s, const BestRec *__restrict__ partial, int n_partial, int rank_slot,
+                                                BestRec *s_best) {
     const int tid = threadIdx.x;
     BestRec r;
     r.val = INFINITY;
@@ -138,6 +138,13 @@ __global__ __launch_bounds__(256) void candidate_kernel(gdpso_swarm s, int itera
         rec[1] = have ? (double)r.idx : -1.0;
     }
     for (int k = tid; k < s.d; k += 256) rec[2 + k] = have ? s.pbest_pos[(size_t)(r.idx - s.first_index) * s.d + k] : 0.0;
+}
+
+__global__ __launch_bounds__(256) void candidate_kernel(gdpso_swarm s, int iteration, const BestRec *__restrict__ partial,
+                                                        int n_partial, int rank_slot) {
+    __shared__ BestRec s_best[4];
+    if (!running(s.ctrl, iteration)) return;
+    write_candidate(s, partial, n_partial, rank_slot, s_best);
 }
 
 // update_global_best (util_pso.py:135-151) over the candidate records of all ranks, the
@@ -192,6 +199,25 @@ __global__ __launch_bounds__(64) void global_best_kernel(gdpso_swarm s, int iter
     if (slot >= 0) {
         const double *rec = cand_row(s, slot);
         for (int k = tid; k < s.d; k += 64) s.gbest_pos[k] = rec[2 + k];
+    }
+}
+
+// Single process: the candidate record and the global-best update it feeds in one launch.
+__global__ __launch_bounds__(256) void candidate_global_kernel(gdpso_swarm s, int iteration, const BestRec *__restrict__ partial,
+                                                               int n_partial, int schedule_inertia, int early_stopping,
+                                                               double tolerance) {
+    __shared__ BestRec s_best[4];
+    __shared__ int s_take;
+    if (!running(s.ctrl, iteration)) return;
+    write_candidate(s, partial, n_partial, 0, s_best);
+    __threadfence_block();
+    __syncthreads();
+    const int tid = threadIdx.x;
+    if (tid == 0) s_take = decide_global_best(s, iteration, schedule_inertia, early_stopping, tolerance);
+    __syncthreads();
+    if (s_take >= 0) {
+        const double *rec = cand_row(s, s_take);
+        for (int k = tid; k < s.d; k += 256) s.gbest_pos[k] = rec[2 + k];
     }
 }
 
@@ -801,8 +827,12 @@ extern "C" int gdpso_swarm_iterate(const gdpso_swarm *s, const gdpso_generator *
                                (r->f32_first_move && i == 1) ? 1 : 0);
             GDPSO_HIP(hipGetLastError());
         } else {
-            if ((rc = gdpso_swarm_local_best(s, stream, i, 0))) return rc;
-            if ((rc = gdpso_swarm_global_best(s, stream, i, r->schedule_inertia, r->early_stopping, r->tolerance))) return rc;
+            GDPSO_REQUIRE(gdpso_swarm_scratch_bytes(s->n) <= s->scratch_bytes, "swarm_iterate: scratch too small");
+            const int nb = ceil_div(s->n, PB);
+            hipLaunchKernelGGL(pbest_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *s, i, (BestRec *)s->scratch);
+            hipLaunchKernelGGL(candidate_global_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *s, i, (const BestRec *)s->scratch, nb,
+                               r->schedule_inertia, r->early_stopping, r->tolerance);
+            GDPSO_HIP(hipGetLastError());
             if ((rc = gdpso_swarm_move(s, stream, i, r->w_cogn, r->w_soci, rnd, r->seed, r->f32_first_move))) return rc;
         }
         if (r->diagnostics && s->mean_dist && s->n >= 2)
