@@ -13,9 +13,16 @@
 
 namespace gdpso {
 
-// particles per workgroup in the personal-best kernel: few, because a workgroup also copies the improved
-// particles' positions (PB x d doubles) and at 512 particles x 100 dimensions two workgroups of 256 took 16.7 us
-constexpr int PB = 32;
+// Particles per workgroup in the personal-best kernel: PB at least (what the scratch buffer's layout is
+// sized by), up to PB_MAX once that still leaves eight workgroups per compute unit (pbest_particles).  Few for
+// small swarms, because a workgroup also copies the improved particles' positions (d doubles each): at 512
+// particles x 100 dimensions two workgroups of 256 particles took 16.7 us, sixteen of 32 take 4.
+constexpr int PB = 32, PB_MAX = 256;
+static int pbest_particles(int n) {
+    int pb = PB_MAX;
+    while (pb > PB && (n + pb - 1) / pb < 2048) pb >>= 1;
+    return pb;
+}
 
 struct BestRec {
     float val;
@@ -85,18 +92,18 @@ __global__ __launch_bounds__(256) void reset_kernel(gdpso_swarm s, double w_iner
 }
 
 // update_personal_best: "if fitness < p_best_val: p_best_val, p_best_pos = fitness, pos"
-// (util_pso.py:122-124) for PB particles per workgroup, then the workgroup's min-loc over
+// (util_pso.py:122-124) for pb particles per workgroup, then the workgroup's min-loc over
 // the updated personal bests -> partial[blockIdx.x].
-__global__ __launch_bounds__(256) void pbest_kernel(gdpso_swarm s, int iteration, BestRec *__restrict__ partial) {
-    __shared__ unsigned char s_better[PB];
+__global__ __launch_bounds__(256) void pbest_kernel(gdpso_swarm s, int iteration, BestRec *__restrict__ partial, int pb) {
+    __shared__ unsigned char s_better[PB_MAX];
     __shared__ BestRec s_best[4];
     if (!running(s.ctrl, iteration)) return;
-    const int tid = threadIdx.x, p0 = blockIdx.x * PB, p = p0 + tid;
+    const int tid = threadIdx.x, p0 = blockIdx.x * pb, p = p0 + tid;
     BestRec r;
     r.val = INFINITY;
     r.idx = 0x7fffffff;
     bool better = false;
-    if (tid < PB && p < s.n) {
+    if (tid < pb && p < s.n) {
         const float f = s.fitness[p];
         float pb = s.pbest_val[p];
         better = f < pb;
@@ -107,12 +114,12 @@ __global__ __launch_bounds__(256) void pbest_kernel(gdpso_swarm s, int iteration
         r.val = pb;
         r.idx = s.first_index + p;
     }
-    if (tid < PB) s_better[tid] = better;
+    if (tid < pb) s_better[tid] = better;
     r = wave_best(r);
     if ((tid & 63) == 0) s_best[tid >> 6] = r;
     __syncthreads();
     if (tid == 0) partial[blockIdx.x] = better_of(better_of(s_best[0], s_best[1]), better_of(s_best[2], s_best[3]));
-    const int cnt = min(PB, s.n - p0);
+    const int cnt = min(pb, s.n - p0);
     const long base = (long)p0 * s.d;
     for (int e = tid; e < cnt * s.d; e += 256)
         if (s_better[e / s.d]) s.pbest_pos[base + e] = s.pos[base + e];
@@ -683,8 +690,8 @@ extern "C" int gdpso_swarm_local_best(const gdpso_swarm *s, void *stream, int it
         return GDPSO_OK;
     }
     BestRec *partial = (BestRec *)s->scratch;
-    const int nb = ceil_div(s->n, PB);
-    hipLaunchKernelGGL(pbest_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *s, iteration, partial);
+    const int pb = pbest_particles(s->n), nb = ceil_div(s->n, pb);
+    hipLaunchKernelGGL(pbest_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *s, iteration, partial, pb);
     hipLaunchKernelGGL(candidate_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *s, iteration, partial, nb, rank_slot);
     GDPSO_HIP(hipGetLastError());
     return GDPSO_OK;
@@ -828,8 +835,8 @@ extern "C" int gdpso_swarm_iterate(const gdpso_swarm *s, const gdpso_generator *
             GDPSO_HIP(hipGetLastError());
         } else {
             GDPSO_REQUIRE(gdpso_swarm_scratch_bytes(s->n) <= s->scratch_bytes, "swarm_iterate: scratch too small");
-            const int nb = ceil_div(s->n, PB);
-            hipLaunchKernelGGL(pbest_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *s, i, (BestRec *)s->scratch);
+            const int pb = pbest_particles(s->n), nb = ceil_div(s->n, pb);
+            hipLaunchKernelGGL(pbest_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *s, i, (BestRec *)s->scratch, pb);
             hipLaunchKernelGGL(candidate_global_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *s, i, (const BestRec *)s->scratch, nb,
                                r->schedule_inertia, r->early_stopping, r->tolerance);
             GDPSO_HIP(hipGetLastError());
