@@ -255,7 +255,9 @@ def mean_pairwise_distance(pos: np.ndarray) -> float:
 
 def pairwise_distance_part(pos: np.ndarray, part: int, n_parts: int) -> float:
     """Sum of the Euclidean distances of the pairs (i < j) with i % n_parts == part: one of n_parts
-    pieces of the sum behind mean_pairwise_distance (the pieces add up to mean * n (n - 1) / 2)."""
+    pieces of the sum behind mean_pairwise_distance (reference util_pso.py:76-86; the pieces add up to
+    mean * n (n - 1) / 2).  The reference computes the whole sum in one process; the pieces exist to check
+    the multi-process loop, which shares the work between its ranks."""
     n = pos.shape[0]
     iu = np.triu_indices(n, 1)
     keep = iu[0] % n_parts == part
