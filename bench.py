@@ -119,6 +119,9 @@ def launch_ranks(n_ranks, argv):
     return proc.returncode
 
 
+N_PHASE_PASSES, N_PHASE_TIMED = 48, 18  # generator / assessor passes ahead of the warm-up steps, and how many of them are timed
+
+
 def dry_run(args, world, rank, result_fd):
     """GDPSO_BENCH_DRYRUN=1: everything around the measurement without a GPU (rendezvous of the
     ranks over gloo, one exchange of candidate records and positions through engine.TorchComm, the
@@ -268,6 +271,24 @@ def main():
             comm.dist.barrier()
             torch.cuda.synchronize(dev)
 
+    # First pass, every rank: where an iteration's time goes.  Generator and assessor are run on the swarm's
+    # positions as calls of their own, back to back without a host synchronisation, with HIP events between
+    # them on the launch stream; the PSO update (personal / global best, move, history) and the distance
+    # diagnostic are what an iteration of the timed loop takes beyond the two.  It runs ahead of the warm-up
+    # steps because it also brings the device from idle to its working clock, which takes ~25 iterations
+    # (tools/iter_ramp.py: 0.96 ms per iteration at first, 0.83 from the 26th on, again after every idle
+    # second); the numbers come from its last passes.
+    marks = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(N_PHASE_PASSES)]
+    for it in range(N_PHASE_PASSES):
+        marks[it][0].record()
+        img01, _, _ = ev.images(sw.pos)
+        marks[it][1].record()
+        ev.assess(img01, spec)
+        marks[it][2].record()
+    torch.cuda.synchronize(dev)
+    gen_ms = float(np.mean([m[0].elapsed_time(m[1]) for m in marks[-N_PHASE_TIMED:]]))
+    ass_ms = float(np.mean([m[1].elapsed_time(m[2]) for m in marks[-N_PHASE_TIMED:]]))
+
     run(1, w)
     dbg("warm-up enqueued")
     fence()
@@ -327,27 +348,12 @@ def main():
                     "executed_frac": round(executed / (ms.value * 1e-3) / 1e12 / peak, 4),
                     # the same launches priced against HBM: algorithmic bytes over kernel time
                     "algorithmic_tb_per_s": round(alg_bytes * launches.value / (ms.value * 1e-3) / 1e12, 3)}
-    # third pass, single process only: where an iteration's time goes.  Generator and assessor are run on
-    # the swarm's positions as calls of their own, back to back without a host synchronisation, with HIP
-    # events between them on the launch stream; the PSO update (personal / global best, move, history) and
-    # the distance diagnostic are what an iteration of the timed loop takes beyond the two.
     phases = None
-    if rank == 0 and comm is None:
-        n_ph = 20
-        marks = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n_ph)]
-        for it in range(n_ph):
-            marks[it][0].record()
-            img01, _, _ = ev.images(sw.pos)
-            marks[it][1].record()
-            ev.assess(img01, spec)
-            marks[it][2].record()
-        torch.cuda.synchronize(dev)
-        gen_ms = float(np.mean([m[0].elapsed_time(m[1]) for m in marks[2:]]))
-        ass_ms = float(np.mean([m[1].elapsed_time(m[2]) for m in marks[2:]]))
+    if gen_ms is not None and comm is None:
         phases = {"generator_ms": round(gen_ms, 4), "assessor_ms": round(ass_ms, 4),
                   "pso_update_and_diagnostic_ms": round(max(0.0, 1e3 * dt / k - gen_ms - ass_ms), 4), "collective_ms": None,
-                  "how": f"HIP events on the launch stream around {n_ph - 2} generator / assessor passes enqueued back to back; "
-                         "the rest = ms_per_step of the timed loop minus the two"}
+                  "how": f"HIP events on the launch stream around the last {N_PHASE_TIMED} of {N_PHASE_PASSES} generator / assessor passes enqueued "
+                         "back to back ahead of the warm-up steps; the rest = ms_per_step of the timed loop minus the two"}
     if comm is not None:
         comm.dist.barrier()
 
@@ -363,6 +369,8 @@ def main():
                        "flop_per_particle_eval": flop_per_eval, "parallelism": f"particle shards x{world}"},
             "end_to_end_tflops": round(value * flop_per_eval / 1e12, 3),
             "host_enqueue_ms_per_step": round(1e3 * t_enqueued / k, 4),
+            "order": f"{N_PHASE_PASSES} generator / assessor passes (per-phase timing; they also take the device from idle to its working "
+                     f"clock), {w} warm-up steps, {k} timed steps, {k} more steps with HIP events around every convolution launch (roofline)",
             "roofline": roofline,
             "phases": phases,
         }

@@ -103,6 +103,7 @@ struct ChainWait {
     unsigned target = 0;
     int count = 0;
     unsigned *status = nullptr;
+    int peek = 1;
 #ifdef GDPSO_STAMPS
     unsigned long long *stamp = nullptr;  // diagnostic build: where to note the time the wait ended
     unsigned long long *tile_stamps = nullptr;  // ... and where the tile code's own stamps go (null: not this tile)
@@ -129,15 +130,18 @@ __device__ __forceinline__ void chain_abort(unsigned *status, unsigned bit) {
 // CU's L1), then the workgroup meets at a barrier.  No read-modify-write anywhere: arrivals at one
 // counter serialise in the L2 (64 of them cost 1.6 us, measured by tools/micro/xcd_barrier.hip), plain
 // stores to words of their own do not.  The memory clobber keeps the activation loads behind the wait.
-__device__ __forceinline__ void chain_wait(const ChainWait &w, int tid) {
+// `early`: what chain_peek read from the lane's flag word at the top of the tile; the first check uses it.
+__device__ __forceinline__ void chain_wait(const ChainWait &w, int tid, unsigned early) {
     if (w.flags == nullptr) return;
     if (tid < 64) {
         unsigned spins = 0;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         for (int base = 0; base < w.count; base += 64) {
+            bool fresh = base == 0;
             for (;;) {
                 const int m = base + tid;
-                const unsigned f = m < w.count ? __hip_atomic_load(w.flags + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+                const unsigned f = fresh ? early : m < w.count ? __hip_atomic_load(w.flags + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+                fresh = false;
                 if (__all((int)(f >= w.target))) break;
                 ++spins;
                 if ((spins & 255u) == 0) {
@@ -156,6 +160,16 @@ __device__ __forceinline__ void chain_wait(const ChainWait &w, int tid) {
 #ifdef GDPSO_STAMPS
     if (w.stamp && tid == 0) *w.stamp = __builtin_amdgcn_s_memrealtime();
 #endif
+}
+
+// The first look at the flags, taken at the very top of a tile so that the load's round trip to the L2
+// (~0.7 us) runs under the tile's prologue: the workgroup that finished the previous step last comes to
+// its wait when everybody else has long published, and would otherwise pay that round trip in full on
+// what is the critical path of the step.
+__device__ __forceinline__ unsigned chain_peek(const ChainWait &w, int tid) {
+    if (w.flags == nullptr || tid >= 64) return 0u;
+    if (!w.peek) return 0u;
+    return tid < w.count ? __hip_atomic_load(w.flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
 }
 
 // What a workgroup needs to know about its phase (all wave-uniform).
@@ -417,6 +431,8 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
 #endif
     GDPSO_STAMP(0)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned flags_early = 0u;
+    if constexpr (CHAIN) flags_early = chain_peek(wait, tid);
     const int wr = KW == 1 ? wave >> 1 : 0, wc = KW == 4 ? 0 : wave & 1, kh = KW == 1 ? 0 : (KW == 2 ? wave >> 1 : wave);
     const int l31 = lane & 31, half = lane >> 5;
 
@@ -629,7 +645,7 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
             // weights first; the activations only once the layer that writes them has finished in this share
             GDPSO_GISSUE_B(0)
             GDPSO_STAMP(11)  // weights requested, the wait begins
-            chain_wait(wait, tid);
+            chain_wait(wait, tid, flags_early);
             GDPSO_STAMP(12)
             GDPSO_GISSUE_A(0)
             GDPSO_GADVANCE()
@@ -982,7 +998,7 @@ __device__ int g_chain_stamp_step = -1;  // the step whose tiles also leave the 
 
 template <typename E>
 __global__ __launch_bounds__(256, 2) void conv_chain_kernel(const ChainStep *steps, int nsteps, char *ws, ChainCtl *ctl,
-                                                             unsigned drop_xcc_mask, int nteams, unsigned stagger_ticks) {
+                                                             unsigned drop_xcc_mask, int nteams, unsigned stagger_ticks, int peek) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 64 * 132];  // the largest of the three tile shapes
     __shared__ int s_reg[12];
     const int tid = threadIdx.x;
@@ -1086,6 +1102,7 @@ __global__ __launch_bounds__(256, 2) void conv_chain_kernel(const ChainStep *ste
                 const int slot = t - (which ? ta : 0);
                 const int shape = meta[2 + which];
                 ChainWait w;
+                w.peek = peek;
                 if (first && s > 0) {
                     w.flags = ctl->flags[share];
                     w.target = (unsigned)s;  // step s - 1 finished
@@ -1483,6 +1500,10 @@ static unsigned g_chain_stagger = [] {
     const char *e = getenv("GDPSO_CHAIN_STAGGER_US");
     return (unsigned)(100.0 * (e ? atof(e) : 6.0));  // s_memrealtime ticks (100 MHz)
 }();
+static int g_chain_peek = [] {
+    const char *e = getenv("GDPSO_CHAIN_PEEK");
+    return e ? atoi(e) : 1;
+}();
 int chain_teams() { return g_chain_teams; }
 
 struct ConvChain {
@@ -1650,7 +1671,7 @@ int launch_chain(const ConvChain *c, hipStream_t stream, void *workspace, bool c
     if (timed) {
         GDPSO_WITH_DTYPE(c->dtype, hipExtLaunchKernelGGL(conv_chain_kernel<E>, grid, dim3(256), 0, stream, g_timing.events[g_timing.used],
                                                          g_timing.events[g_timing.used + 1], 0, (const ChainStep *)c->dev_steps,
-                                                         (int)c->steps.size(), ws, ctl, g_chain_drop_mask, c->nteams, g_chain_stagger));
+                                                         (int)c->steps.size(), ws, ctl, g_chain_drop_mask, c->nteams, g_chain_stagger, g_chain_peek));
         g_timing.used += 2;
         size_t li = 0;
         for (const ChainStep &st : c->steps)
@@ -1661,7 +1682,7 @@ int launch_chain(const ConvChain *c, hipStream_t stream, void *workspace, bool c
                 }
     } else {
         GDPSO_WITH_DTYPE(c->dtype, hipLaunchKernelGGL(conv_chain_kernel<E>, grid, dim3(256), 0, stream, (const ChainStep *)c->dev_steps,
-                                                      (int)c->steps.size(), ws, ctl, g_chain_drop_mask, c->nteams, g_chain_stagger));
+                                                      (int)c->steps.size(), ws, ctl, g_chain_drop_mask, c->nteams, g_chain_stagger, g_chain_peek));
     }
     GDPSO_HIP(hipGetLastError());
     ++g_chain_launches;
