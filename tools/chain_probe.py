@@ -80,6 +80,15 @@ def main():
         # the tile code's own stamps (s_memtime ticks; slots 7 / 6 hold s_memrealtime at entry / exit) of the first tile
         # each workgroup ran in that step
         ts = tbuf.cpu().numpy().astype(np.int64)
+        # per workgroup: its own signal of the previous step -> entry of this step -> entry of the tile code
+        # (the step's arguments fetched in between), on the 100 MHz clock
+        both = (ts[:512, 11] != 0) & (s[:, tile_step, 0] > 0) & (s[:, tile_step - 1, 3] > 0)
+        gap = s[both, tile_step, 0] - s[both, tile_step - 1, 3]
+        args = ts[:512, 7][both] * 0.01 - s[both, tile_step, 0]
+        whole = np.where(s[both, tile_step, 1] > 0, s[both, tile_step, 1], s[both, tile_step, 0]) - s[both, tile_step - 1, 3]
+        print(f"step {tile_step}: own signal of step {tile_step - 1} -> step entry {np.median(gap):.2f} ({np.percentile(gap, 90):.2f}); "
+              f"step entry -> tile code entered {np.median(args):.2f} ({np.percentile(args, 90):.2f}); "
+              f"own signal -> own wait ended {np.median(whole):.2f} ({np.percentile(whole, 90):.2f})")
         ts = ts[ts[:, 11] != 0]  # rows stamped by the chain (only it has slot 11)
         ghz = float(np.median((ts[:, 3] - ts[:, 0]) / np.maximum(1, (ts[:, 6] - ts[:, 7]) * 10.0)))
         print(f"step {tile_step}: {ts.shape[0]} workgroups stamped, in-kernel clock ~{ghz:.2f} GHz; medians (p90) in us:")
