@@ -16,15 +16,17 @@ import pytest
 from conftest import ROOT, load_golden
 
 
-@pytest.mark.parametrize("world,table", [(2, False), (2, True), (3, False)])
-def test_sharded_loop_matches_reference(tmp_path, world, table):
+@pytest.mark.parametrize("world,table,beside", [(2, False, False), (2, True, False), (3, False, False), (3, False, True)])
+def test_sharded_loop_matches_reference(tmp_path, world, table, beside):
     """One all-gather of the candidate records per iteration.  world 2, equal shards: the positions
     either follow every move in a gather of their own (the ranks' distance sums then ride in the next
     records) or lie in the exchange table behind the records (no other collective, the diagnostic two
     exchanges behind); world 3: unequal shards (22 + 21 + 21), positions gathered as padded blocks."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", GDPSO_TEST_TABLE_POSITIONS="1" if table else "0")
+    if beside:  # the positions' gather as an asynchronous collective that the loop waits for one iteration later
+        env["GDPSO_COMM_ASYNC_BYTES"] = "0"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(29500 + 2 * world + int(table)), os.path.join(ROOT, "tests", "sharded_worker.py"), str(tmp_path)]
+           "--master-port", str(29500 + 4 * world + 2 * int(table) + int(beside)), os.path.join(ROOT, "tests", "sharded_worker.py"), str(tmp_path)]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr[-2000:]
     g = load_golden("swarm_n64_t50_z10")
