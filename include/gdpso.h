@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define GDPSO_ABI_VERSION 1
+/* 2: gdpso_swarm gained cand_stride and the candidate records two distance-sum slots (GDPSO_CAND_DOUBLES) */
+#define GDPSO_ABI_VERSION 2
 
 #define GDPSO_OK 0
 #define GDPSO_ERR_ARG 1       /* bad argument / unsupported shape */
