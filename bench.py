@@ -35,7 +35,8 @@ sys.path.insert(0, ROOT)
 # MI355X dense matrix-instruction peaks by operand type: fp32-input MFMA (= the fp32 vector peak), and
 # the 16-bit forms (about 2.5 PFLOP/s dense; the headline figures twice that include 2:1 sparsity)
 PEAK_MFMA_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0}
-TRAFFIC_FILE = "r2_hbm_traffic.json"  # PMC summary of the default command (tools/refresh_profiles.sh)
+# PMC summaries (tools/refresh_profiles.sh) of the configurations that have one: (dtype, z_dim, side, particles) -> file
+TRAFFIC_FILES = {("f32", 10, 28, 512): "r3_hbm_traffic.json", ("bf16", 100, 28, 512): "r3_bf16_hbm_traffic.json"}
 
 
 def _cpu_model():
@@ -119,17 +120,99 @@ def launch_ranks(n_ranks, argv):
     return proc.returncode
 
 
+def reference_run_shape(eng, ev, spec, z_dim, dev):
+    """The shape the reference really runs (configs/dcgan_mnist.yaml:146-156, src/training/pso_discovery.py:174-218),
+    beside the steady-state headline: (a) one swarm of the benchmark's size for T = 50 iterations started on a
+    device that has idled (the clock ramp is inside the run); (b) its 8 classes x 32 particles x 50 iterations,
+    every iteration of the 8 swarms as one batch, from an idle device too."""
+    import time as _time
+    p, t = 512, 50
+    rs = np.random.RandomState(43)
+    r = rs.standard_normal((p, 2, z_dim))
+    sw = eng.HipSwarm(ev, p, z_dim, t, history=True, diagnostics=True)
+    sw.load(r[:, 0], (r[:, 1] - 0.5) / 10, 0.73)
+    torch.cuda.synchronize(dev)
+    _time.sleep(1.5)  # long enough for the device to fall back to its idle clock
+    t0 = _time.perf_counter()
+    sw.iterate(1, t, spec, 1.496, 1.496, False, False, 1e-5, True, seed=42)
+    torch.cuda.synchronize(dev)
+    cold = _time.perf_counter() - t0
+    sizes, iters = [32] * 8, [t] * 8
+    batch = eng.HipSwarmBatch(ev, sizes, z_dim, iters, history=True, diagnostics=True)
+    specs = [eng.FitnessSpec(class_index=c) for c in range(8)]
+    params = [dict(w_cogn=1.496, w_soci=1.496, schedule_inertia=False, early_stopping=False, tolerance=1e-5, diagnostics=True, seed=7 + c)
+              for c in range(8)]
+
+    def load():
+        for c, s in enumerate(batch.swarms):
+            q = np.random.RandomState(100 + c).standard_normal((32, 2, z_dim))
+            s.load(q[:, 0], (q[:, 1] - 0.5) / 10, 0.73)
+
+    load()
+    batch.iterate(1, 2, specs, params)  # plans and buffers of the 256-image batch
+    torch.cuda.synchronize(dev)
+    load()
+    _time.sleep(1.5)
+    t0 = _time.perf_counter()
+    batch.iterate(1, t, specs, params)
+    torch.cuda.synchronize(dev)
+    multi = _time.perf_counter() - t0
+    return {"t50_from_idle_ms_per_iteration": round(1e3 * cold / t, 4), "t50_from_idle_particle_evals_per_s": round(p * t / cold, 1),
+            "multi_swarm_8x32_t50_ms_per_iteration": round(1e3 * multi / t, 4),
+            "multi_swarm_8x32_t50_particle_evals_per_s": round(256 * t / multi, 1),
+            "how": "wall clock around 50 iterations enqueued at once on a device that has idled for 1.5 s (host synchronised either side); "
+                   "not the headline: `value` is the steady state"}
+
+
 N_PHASE_PASSES, N_PHASE_TIMED = 48, 18  # generator / assessor passes ahead of the warm-up steps, and how many of them are timed
+
+
+def rank_spread(dist, dt, device=None):
+    """(max, min) of a per-rank duration over the ranks."""
+    hi = torch.tensor([dt], dtype=torch.float64, device=device)
+    lo = hi.clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    return float(hi.item()), float(lo.item())
+
+
+def result_line(args, world, *, value, dt, dt_min, k, w, n_global, p, z_dim, side, flop_per_eval, t_enqueued, roofline, phases, ranks_seen,
+                extra=None):
+    """The one JSON object rank 0 prints (the dry run fills it with what it has, so that both carry the same keys)."""
+    ms = None if dt is None else round(1e3 * dt / k, 4)
+    out = {
+        "metric": "particle-evaluations/sec (swarm x gen-fwd) DCGAN-MNIST", "value": None if value is None else round(value, 1),
+        "unit": "particle-evals/s", "n_gpus": world, "steps": k, "warmup": w, "ms_per_step": ms,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"DCGAN-MNIST {side}x{side}, {p} particles per GPU, ResNet50 assessor (n_class=8), z_dim={z_dim}, "
+                               f"{n_global} particles total", "particles_per_gpu": p, "z_dim": z_dim,
+                   "flop_per_particle_eval": flop_per_eval, "parallelism": f"particle shards x{world}"},
+        "end_to_end_tflops": None if value is None or flop_per_eval is None else round(value * flop_per_eval / 1e12, 3),
+        "host_enqueue_ms_per_step": None if t_enqueued is None else round(1e3 * t_enqueued / k, 4),
+        "order": f"{N_PHASE_PASSES} generator / assessor passes (per-phase timing; they also take the device from idle to its working "
+                 f"clock: the driver's --warmup steps come behind them), {w} warm-up steps, {k} timed steps, "
+                 + (f"{k} more steps of the sharded loop with HIP events either side of the all-gather (collective_ms), " if world > 1 or (phases or {}).get("collective_ms") is not None else "")
+                 + f"{k} more steps with HIP events around every convolution launch (roofline)",
+        "roofline": roofline,
+        "phases": phases,
+        # per-rank spread of the timed region (value uses the slowest rank)
+        "ranks": {"n_ranks_seen": ranks_seen, "ms_per_step_max": ms, "ms_per_step_min": None if dt_min is None else round(1e3 * dt_min / k, 4)},
+    }
+    out.update(extra or {})
+    return out
 
 
 def dry_run(args, world, rank, result_fd):
     """GDPSO_BENCH_DRYRUN=1: everything around the measurement without a GPU (rendezvous of the
     ranks over gloo, one exchange of candidate records and positions through engine.TorchComm, the
-    max-over-ranks reduction, rank 0's result line), so that the launch path of `--gpus N` can be
-    tested where there is no GPU.  The line says "dry_run": true and carries no value."""
+    max- and min-over-ranks reductions, rank 0's result line with every key of a real one), so that the
+    launch path of `--gpus N` can be tested where there is no GPU.  The line says "dry_run": true, its
+    times are made up (rank r "takes" r + 1 ms a step) and it carries no value."""
     import torch.distributed as dist
     eng = importlib.import_module("gan-discovery-pso_amd.engine")
     lib = importlib.import_module("gan-discovery-pso_amd._lib")
+    k = args.steps
+    dt, dt_min, coll_ms, seen = 1e-3 * k, 1e-3 * k, None, 1
     if world > 1:
         dist.init_process_group(backend="gloo")
         comm = eng.TorchComm()
@@ -139,18 +222,23 @@ def dry_run(args, world, rank, result_fd):
         pos = torch.full((p, d), float(rank), dtype=torch.float64)
         handle = comm.start_gather_positions(pos, world * p)
         cand[rank, d + 2] = 10.0 + rank
+        t0 = time.perf_counter()
         comm.all_gather(cand, cand[rank])
+        coll_ms = 1e3 * (time.perf_counter() - t0)
         allp = handle.wait()
         assert cand[:, 1].tolist() == [float(r * p) for r in range(world)]
         assert cand[:, d + 2].tolist() == [10.0 + r for r in range(world)]
         assert allp[:, 0].tolist() == [float(r) for r in range(world) for _ in range(p)]
-        t = torch.tensor([float(rank)], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        assert t.item() == world - 1
+        dt, dt_min = rank_spread(dist, 1e-3 * k * (rank + 1))
+        assert (dt, dt_min) == (1e-3 * k * world, 1e-3 * k)
+        seen = dist.get_world_size()
         dist.barrier()
     if rank == 0:
-        out = {"metric": "particle-evaluations/sec (swarm x gen-fwd) DCGAN-MNIST", "value": None, "unit": "particle-evals/s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True}
+        phases = {"generator_ms": None, "assessor_ms": None, "pso_update_and_diagnostic_ms": None,
+                  "collective_ms": None if coll_ms is None else round(coll_ms, 4), "how": "dry run: one host-timed gloo all-gather"}
+        out = result_line(args, world, value=None, dt=dt, dt_min=dt_min, k=k, w=args.warmup, n_global=args.particles * world,
+                          p=args.particles, z_dim=args.z_dim, side=args.side, flop_per_eval=None, t_enqueued=None, roofline=None,
+                          phases=phases, ranks_seen=seen, extra={"dry_run": True})
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
@@ -168,6 +256,8 @@ def main():
                     help="storage / matrix-instruction input type of the networks (f32: the reference's precision and the headline "
                          "configuration; bf16: the VQ-VAE-decoder configuration with --z-dim 100; f16: the 64x64 one with --side 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reference-shape", action="store_true",
+                    help="skip the two extra measurements of the reference's own run shape (T = 50 from an idle device; 8 swarms x 32 particles)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -297,14 +387,31 @@ def main():
     run(w + 1, k)
     t_enqueued = time.perf_counter() - t0  # host time to enqueue the K steps (the device runs behind it)
     fence()
-    dt = time.perf_counter() - t0
+    dt = dt_min = time.perf_counter() - t0
+    ranks_seen = 1
     if comm is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        comm.dist.all_reduce(t, op=comm.dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, dt_min = rank_spread(comm.dist, dt, dev if backend == "nccl" else None)
+        ranks_seen = comm.dist.get_world_size()
     dbg("timed region done")
     ctrl = sw.control()
     assert int(ctrl[lib.CTRL_ITERS_DONE]) == w + k, "the loop did not run every iteration"
+
+    # With a process group, every rank: K more steps of the sharded loop with HIP events on the launch stream
+    # either side of the all-gather (the one collective of an iteration; it runs in stream order there).
+    coll_ms = None
+    if comm is not None:
+        ev_pairs = [[torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)] for _ in range(k)]
+
+        def mark(i, name):
+            j = i - (w + k + 1)
+            if 0 <= j < k and name == "local_best":
+                ev_pairs[j][0].record()
+            elif 0 <= j < k and name == "exchange":
+                ev_pairs[j][1].record()
+
+        eng.sharded_iterations(sw, comm, w + k + 1, k, spec, 1.496, 1.496, False, False, 1e-5, True, seed=42, after_phase=mark)
+        fence()
+        coll_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_pairs]))
 
     # second pass of K steps with HIP events around every convolution launch (same stream)
     roofline = None
@@ -325,20 +432,29 @@ def main():
         executed = L.gdpso_conv_timing_executed_flops()
         # HBM bytes per launch from the committed PMC passes of this same command (counters cannot be
         # read from inside the process); null when the summary is absent or was taken at another size
-        traffic = None
+        traffic, traffic_file = None, TRAFFIC_FILES.get((args.dtype, z_dim, args.side, p))
         try:
-            with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as f:
-                pm = json.load(f)
-            if p == 512 and z_dim == 10 and args.side == 28 and args.dtype == "f32":
-                traffic = pm["kernels"]["conv_gemm (all instantiations)"]["hbm_bytes_per_launch"]
+            if traffic_file:
+                with open(os.path.join(ROOT, "profiles", traffic_file)) as f:
+                    traffic = json.load(f)["kernels"]["conv_gemm (all instantiations)"]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
         peak = PEAK_MFMA_TFLOPS[args.dtype]
-        roofline = {"bound": "mfma", "kernel": f"conv_chain_kernel (the ResNet stages behind the first in one persistent launch, fp32) / conv_gemm_kernel / conv_gemm_pair_kernel / "
+        tb_per_s = alg_bytes * launches.value / (ms.value * 1e-3) / 1e12
+        # fp32-input MFMA is slow enough for the matrix pipe to be the roof.  With 16-bit inputs the pipe is 16x
+        # faster and these layers are short: neither roof is near, what bounds the launches is the fixed cost of a
+        # tile and of a step of the chained launch (prologue, hand-off, operand fetch, epilogue)
+        bound = "mfma" if args.dtype == "f32" else "latency"
+        roofline = {"bound": bound,
+                    "bound_note": None if bound == "mfma" else
+                    f"neither roof is near (matrix pipe {achieved / peak:.3f} of its peak, HBM {tb_per_s / 8.0:.3f} of 8 TB/s on the algorithmic bytes): "
+                    "per-tile and per-step fixed costs (prologue, hand-off between dependent layers, operand fetch, epilogue); "
+                    "`frac` prices the launches against the 16-bit MFMA peak all the same",
+                    "kernel": f"conv_chain_kernel (the ResNet stages behind the first in one persistent launch) / conv_gemm_kernel / conv_gemm_pair_kernel / "
                               f"conv_gemm_fused_kernel, all instantiations: one tile code ({args.dtype}-input MFMA implicit GEMM)",
                     "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic,
-                    "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/" + TRAFFIC_FILE + ")",
+                    "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE" + (", profiles/" + traffic_file if traffic_file else "; no PMC summary of this configuration") + ")",
                     "algorithmic_bytes_per_launch": round(alg_bytes),
                     "launches_per_step": launches.value // k, "avg_launch_us": round(1e3 * ms.value / launches.value, 3),
                     "conv_ms_per_step": round(ms.value / k, 4),
@@ -347,33 +463,30 @@ def main():
                     "executed_gflop_per_step": round(executed / k / 1e9, 3),
                     "executed_frac": round(executed / (ms.value * 1e-3) / 1e12 / peak, 4),
                     # the same launches priced against HBM: algorithmic bytes over kernel time
-                    "algorithmic_tb_per_s": round(alg_bytes * launches.value / (ms.value * 1e-3) / 1e12, 3)}
-    phases = None
-    if gen_ms is not None and comm is None:
-        phases = {"generator_ms": round(gen_ms, 4), "assessor_ms": round(ass_ms, 4),
-                  "pso_update_and_diagnostic_ms": round(max(0.0, 1e3 * dt / k - gen_ms - ass_ms), 4), "collective_ms": None,
-                  "how": f"HIP events on the launch stream around the last {N_PHASE_TIMED} of {N_PHASE_PASSES} generator / assessor passes enqueued "
-                         "back to back ahead of the warm-up steps; the rest = ms_per_step of the timed loop minus the two"}
+                    "algorithmic_tb_per_s": round(tb_per_s, 3)}
+    # rank 0's own generator / assessor passes, the all-gather between HIP events (when there is one), and what
+    # an iteration of the timed loop takes beyond them
+    phases = {"generator_ms": round(gen_ms, 4), "assessor_ms": round(ass_ms, 4),
+              "pso_update_and_diagnostic_ms": round(max(0.0, 1e3 * dt / k - gen_ms - ass_ms - (coll_ms or 0.0)), 4),
+              "collective_ms": None if coll_ms is None else round(coll_ms, 4),
+              "how": f"HIP events on the launch stream around the last {N_PHASE_TIMED} of {N_PHASE_PASSES} generator / assessor passes enqueued "
+                     "back to back ahead of the warm-up steps (rank 0's)"
+                     + ("; collective_ms: HIP events on the launch stream either side of the in-place all-gather of the exchange table "
+                        f"(candidate records + positions, {sw.exchange_table[0].numel() * 8} B per rank), mean over {k} steps of a pass of its own, "
+                        "which includes waiting for the slowest rank's records" if coll_ms is not None else "")
+                     + "; the rest = ms_per_step of the timed loop minus the others"}
+    extra = {}
+    if rank == 0 and world == 1 and comm is None and args.dtype == "f32" and not args.no_reference_shape:
+        extra["reference_run_shape"] = reference_run_shape(eng, ev, spec, z_dim, dev)
     if comm is not None:
         comm.dist.barrier()
 
     if rank == 0:
         value = n_global * k / dt
         flop_per_eval = gen.flops_per_image + ass.flops_per_image
-        out = {
-            "metric": "particle-evaluations/sec (swarm x gen-fwd) DCGAN-MNIST", "value": round(value, 1),
-            "unit": "particle-evals/s", "n_gpus": world, "steps": k, "warmup": w, "ms_per_step": round(1e3 * dt / k, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"DCGAN-MNIST {gen.side}x{gen.side}, {p} particles per GPU, ResNet50 assessor (n_class=8), z_dim={z_dim}, "
-                                   f"{n_global} particles total", "particles_per_gpu": p, "z_dim": z_dim,
-                       "flop_per_particle_eval": flop_per_eval, "parallelism": f"particle shards x{world}"},
-            "end_to_end_tflops": round(value * flop_per_eval / 1e12, 3),
-            "host_enqueue_ms_per_step": round(1e3 * t_enqueued / k, 4),
-            "order": f"{N_PHASE_PASSES} generator / assessor passes (per-phase timing; they also take the device from idle to its working "
-                     f"clock), {w} warm-up steps, {k} timed steps, {k} more steps with HIP events around every convolution launch (roofline)",
-            "roofline": roofline,
-            "phases": phases,
-        }
+        out = result_line(args, world, value=value, dt=dt, dt_min=dt_min, k=k, w=w, n_global=n_global, p=p, z_dim=z_dim, side=gen.side,
+                          flop_per_eval=flop_per_eval, t_enqueued=t_enqueued, roofline=roofline, phases=phases, ranks_seen=ranks_seen,
+                          extra=extra)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(z_dim, n_class, class_index)
         sys.stdout.flush()

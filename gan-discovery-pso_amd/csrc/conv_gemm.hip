@@ -505,7 +505,13 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
         const int share_rows = a.share_images * P.hm * P.wm;
         m0 += xcd * share_rows;
         P.M = min(P.M, (xcd + 1) * share_rows);
-        if (m0 >= P.M) return;
+        if (m0 >= P.M) {
+            // An empty tile (past the share's rows of this phase) still takes the step's wait when it is the
+            // workgroup's first of the step: the caller hands the wait to the first tile only, and a later
+            // tile of the same workgroup may lie in the non-empty head of the next phase.
+            chain_wait(wait, tid, flags_early);
+            return;
+        }
     }
 #ifdef GDPSO_STAMPS
     asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(wstride), "s"(ntaps) : "memory");  // the phase header has arrived
@@ -1231,7 +1237,22 @@ static long m_tiles(const ConvLayer &L, int n_images, int tile) {
     return t;
 }
 
+// Launch-plan options (gdpso_plan_options).  The tile shape decides the order in which a row's K parts
+// are added (the 32-row shapes split every K-tile over wave pairs or over the four waves, split-K adds
+// slabs), so two batch sizes planned with different shapes agree to fp32 rounding only.  A plan made
+// for a FIXED batch size gives every image the same bits whatever batch it arrives in: that is what
+// makes a sharded run reproduce an unsharded one bit for bit.
+static int g_plan_images = [] {
+    const char *e = getenv("GDPSO_PLAN_IMAGES");
+    return e && atoi(e) > 0 ? atoi(e) : 0;
+}();
+static bool g_plan_splitk = [] {
+    const char *e = getenv("GDPSO_PLAN_SPLITK");
+    return e ? e[0] != '0' : true;
+}();
+
 int plan_conv(ConvLayer &L, int n_images, int num_cus) {
+    if (g_plan_images > 0) n_images = g_plan_images;  // shapes as for that batch size, whatever this one is
     L.tile = 64;
     if (L.cout % 128 == 0) {
         const long t128 = m_tiles(L, n_images, 128) * (L.cout / 128);
@@ -1252,6 +1273,7 @@ int plan_conv(ConvLayer &L, int n_images, int num_cus) {
         // keep at least 128 k per split so the prologue/epilogue stays amortised
         splits = (int)std::max<long>(1, std::min<long>(splits, ktot / 128));
     }
+    if (!g_plan_splitk) splits = 1;
     L.splits = splits;
     return GDPSO_OK;
 }
@@ -1706,6 +1728,17 @@ extern "C" int gdpso_chain_debug(int enabled, unsigned drop_xcc_mask, int teams)
         std::lock_guard<std::mutex> lock(g_chain_streams_mutex);
         g_chain_streams.clear();  // forget the streams seen so far (a test that used several on purpose)
     }
+    return GDPSO_OK;
+}
+
+// Options of launch plans made from now on (handles keep the plans they have already made for a batch
+// size).  plan_images > 0: tile shapes and split counts are chosen as if every batch held that many
+// images (0: each batch by its own size); splitk = 0: K is never split over workgroups.
+extern "C" int gdpso_plan_options(int plan_images, int splitk) {
+    using namespace gdpso;
+    GDPSO_REQUIRE(plan_images >= 0, "plan_options: plan_images must be 0 (off) or a batch size");
+    g_plan_images = plan_images;
+    g_plan_splitk = splitk != 0;
     return GDPSO_OK;
 }
 

@@ -105,13 +105,13 @@ __global__ __launch_bounds__(256) void pbest_kernel(gdpso_swarm s, int iteration
     bool better = false;
     if (tid < pb && p < s.n) {
         const float f = s.fitness[p];
-        float pb = s.pbest_val[p];
-        better = f < pb;
+        float best = s.pbest_val[p];
+        better = f < best;
         if (better) {
-            pb = f;
+            best = f;
             s.pbest_val[p] = f;
         }
-        r.val = pb;
+        r.val = best;
         r.idx = s.first_index + p;
     }
     if (tid < pb) s_better[tid] = better;

@@ -82,6 +82,20 @@ def alexnet_tensors(sd):
     return t, dict(kernel=int(t[0].shape[2]), n_class=int(t[12].shape[0]), to_linear=int(t[8].shape[1]))
 
 
+def alexnet_to_linear(img_side, kernel, padding):
+    """Input width of the reference AlexNet's fc1 (src/pso/util_cnn.py:197-210: four convolutions with
+    MaxPool2d(2) each, 256 channels at the end), or None where a convolution's input is smaller than
+    its window."""
+    pad = (kernel - 1) // 2 if padding == "same" else 0
+    h = img_side
+    for _ in range(4):
+        hc = h + 2 * pad - kernel + 1
+        if hc < 1:
+            return None
+        h = hc // 2
+    return 256 * h * h if h >= 1 else None
+
+
 def encoder_tensors(sd, prefix="enc"):
     """reference src/inverter/utils_ae/util_inverter.py:168-174: enc.0, enc.2.0, enc.3.
     ``prefix="encoder"`` reads the encoder of a VectorQuantizedVAE_GAN, which has a
@@ -99,21 +113,36 @@ def _state_dict_of(model):
 
 
 # ---------------------------------------------------------------------------- handles
-_chain_aborts_seen = 0
+_chain_aborts_seen = {}  # device index -> chain aborts already reported there (the library counts per GPU)
 
 
-def check_chains() -> None:
-    """Raises if a chained convolution launch (several dependent layers in one persistent kernel) gave up
-    waiting for a step since the last call: its outputs, and everything computed from them, are wrong.
-    That happens only when the launch's workgroups cannot all be resident (another process' kernels
-    holding compute units for seconds).  Synchronises the device."""
-    global _chain_aborts_seen
+def check_chains(device=None) -> None:
+    """Raises if a chained convolution launch (several dependent layers in one persistent kernel) on
+    ``device`` (default: the current one) gave up waiting for a step since the last call: its outputs,
+    and everything computed from them, are wrong.  That happens only when the launch's workgroups
+    cannot all be resident (another process' kernels holding compute units for seconds).
+    Synchronises the device."""
+    index = torch.cuda.current_device() if device is None else torch.device(device).index
+    if index is None:
+        index = torch.cuda.current_device()
     n, launches = C.c_uint(0), C.c_uint(0)
-    check(_lib.lib().gdpso_chain_stats(C.byref(launches), C.byref(n)))
-    if n.value != _chain_aborts_seen:
-        _chain_aborts_seen = n.value
+    with torch.cuda.device(index):
+        check(_lib.lib().gdpso_chain_stats(C.byref(launches), C.byref(n)))
+    if n.value != _chain_aborts_seen.get(index, 0):
+        _chain_aborts_seen[index] = n.value
         raise _lib.GdpsoError("a chained convolution launch timed out waiting for its workgroups; results since the last check are invalid "
-                         "(set GDPSO_CONV_CHAIN=0 to run one launch per layer)")
+                              "(set GDPSO_CONV_CHAIN=0 to run one launch per layer)")
+
+
+def plan_options(plan_images: int = 0, splitk: bool = True) -> None:
+    """Options of the launch plans made from now on (gdpso_plan_options; pack the networks AFTER the
+    call: a packed network keeps the plans it has made).  ``plan_images`` > 0 chooses every layer's
+    tile shape as if each batch held that many images: the shape fixes the order of the fp32
+    additions over K, so an image then gets the same bits in a batch of any size, and a swarm
+    sharded over ranks reproduces the unsharded run bit for bit when both plan for the same size
+    (e.g. the ranks' block).  0: every batch by its own size (fastest; results then agree across
+    batch sizes to fp32 rounding only).  ``splitk`` False: never split K over workgroups."""
+    check(_lib.lib().gdpso_plan_options(int(plan_images), int(bool(splitk))))
 
 
 class _Handle:
@@ -204,10 +233,26 @@ class PackedAssessor(_Handle):
             if "fc1.weight" in sd and "conv4.weight" in sd:
                 tensors, self.meta = alexnet_tensors(sd)
                 arr, keep = _lib.host_float_pointers(tensors)
-                args = dict(padding="same", cnn_activation="LeakyReLU")
-                args.update(cnn_args or {})
-                if args["padding"] not in ("same", "valid"):
+                args = dict(cnn_args or {})
+                if args.get("padding") is not None and args["padding"] not in ("same", "valid"):
                     raise ValueError(f"padding {args['padding']!r}: 'same' or 'valid'")
+                # fc1's width fixes the geometry (reference util_cnn.py:207-210 derives it from a dummy
+                # forward pass): the padding is checked against it, or read off it when not given
+                fits = [p for p in ("same", "valid") if alexnet_to_linear(img_side, self.meta["kernel"], p) == self.meta["to_linear"]]
+                if args.get("padding") is None:
+                    if not fits:
+                        raise ValueError(f"AlexNet state dict: fc1 takes {self.meta['to_linear']} features, which neither padding gives "
+                                         f"for {img_side}x{img_side} images and kernel {self.meta['kernel']}")
+                    args["padding"] = fits[0]
+                elif args["padding"] not in fits:
+                    raise ValueError(f"AlexNet state dict: fc1 takes {self.meta['to_linear']} features but padding {args['padding']!r} at "
+                                     f"{img_side}x{img_side} with kernel {self.meta['kernel']} gives "
+                                     f"{alexnet_to_linear(img_side, self.meta['kernel'], args['padding'])}")
+                if args.get("cnn_activation") is None:
+                    import warnings
+                    warnings.warn("AlexNet state dict without cnn_args: the activation cannot be read off the weights, assuming the "
+                                  "reference's default LeakyReLU (pass cnn_args={'cnn_activation': 'ReLU' | 'LeakyReLU', ...})")
+                    args["cnn_activation"] = "LeakyReLU"
                 act = {"ReLU": 1, "LeakyReLU": 2}.get(args["cnn_activation"])
                 if act is None:
                     raise ValueError(args["cnn_activation"])  # the reference's get_activation error (util_cnn.py:54)
@@ -531,7 +576,7 @@ class HipSwarm:
     # -- read-back
     def control(self) -> np.ndarray:
         c = self.ctrl.cpu().numpy()
-        check_chains()
+        check_chains(self.device)
         return c
 
     def results(self) -> dict:
@@ -564,18 +609,20 @@ class HipSwarmBatch:
     slices of two shared buffers."""
 
     def __init__(self, evaluator: Evaluator, sizes, d, max_iters, *, history=True, diagnostics=True, record_fitness=False):
+        """``history`` / ``diagnostics`` / ``record_fitness``: one flag for all the swarms or one per swarm."""
         self.ev, self.device, self.d = evaluator, evaluator.device, int(d)
         self.sizes = [int(n) for n in sizes]
         self.total = sum(self.sizes)
         self.pos_all = torch.zeros(self.total, d, dtype=torch.float64, device=self.device)
         self.fit_all = torch.zeros(self.total, dtype=torch.float32, device=self.device)
         self.swarms, off = [], 0
-        for n, t in zip(self.sizes, max_iters):
-            self.swarms.append(HipSwarm(evaluator, n, d, t, history=history, diagnostics=diagnostics, record_fitness=record_fitness,
+        per_swarm = lambda v: list(v) if isinstance(v, (list, tuple)) else [v] * len(self.sizes)
+        for n, t, h, dg, rf in zip(self.sizes, max_iters, per_swarm(history), per_swarm(diagnostics), per_swarm(record_fitness)):
+            self.swarms.append(HipSwarm(evaluator, n, d, t, history=bool(h), diagnostics=bool(dg), record_fitness=bool(rf),
                                         pos=self.pos_all[off:off + n], fitness=self.fit_all[off:off + n]))
             off += n
         self.max_iter = max(int(t) for t in max_iters)
-        self.class_per_image = None
+        self.class_per_image, self._class_key = None, None
 
     def iterate(self, first, count, specs, params):
         """Iterations first .. first+count-1 of every swarm.  specs: one FitnessSpec per swarm (mode,
@@ -583,9 +630,10 @@ class HipSwarmBatch:
         w_soci, schedule_inertia, early_stopping, tolerance, diagnostics, seed."""
         img, img01, mse = self.ev.image_buffers(self.total)
         ws = self.ev.workspace(self.total)
-        if self.class_per_image is None:
+        class_key = tuple(sp.class_index for sp in specs)
+        if self._class_key != class_key:  # (a later call may come with other classes of interest)
             cls = np.concatenate([np.full(n, sp.class_index, np.int32) for n, sp in zip(self.sizes, specs)])
-            self.class_per_image = torch.from_numpy(cls).to(self.device)
+            self.class_per_image, self._class_key = torch.from_numpy(cls).to(self.device), class_key
         k = len(self.swarms)
         descs = (_lib.SwarmDesc * k)(*[s.desc for s in self.swarms])
         runs = (_lib.RunDesc * k)()
@@ -642,7 +690,7 @@ def run_loop(swarm, n_iterations, spec, w_cogn, w_soci, *, schedule_inertia=Fals
     optional diagnostic's positions ride along with (sharded_iterations).  Nothing here synchronises with the
     device except the periodic early-stop poll.
     """
-    if comm is None or swarm.n_ranks == 1:
+    if comm is None:
         i = 1
         while i <= n_iterations:
             chunk = min(poll_every, n_iterations - i + 1) if early_stopping else n_iterations - i + 1
@@ -656,7 +704,7 @@ def run_loop(swarm, n_iterations, spec, w_cogn, w_soci, *, schedule_inertia=Fals
 
 
 def sharded_iterations(swarm, comm, first, count, spec, w_cogn, w_soci, schedule_inertia, early_stopping, tolerance,
-                       diagnostics, seed=0, poll_every=8, after_phase=None):
+                       diagnostics, seed=0, poll_every=8, after_phase=None, check_every=64):
     """Iterations first .. first+count-1 of the sharded loop.  ONE exchange per iteration lies between
     a rank's fitness values and its move: the all-gather of the exchange table (the candidate records).
 
@@ -672,10 +720,21 @@ def sharded_iterations(swarm, comm, first, count, spec, w_cogn, w_soci, schedule
       iteration's generator and assessor passes, TorchComm.start_gather_positions), the sums travel
       with the records of iteration i+1, and one more exchange at the end flushes the last diagnostic.
 
-    ``after_phase(i, name)`` is a debugging hook.
+    ``after_phase(i, name)`` is a debugging hook.  Every ``poll_every`` iterations (early stopping) or
+    ``check_every`` iterations (otherwise; 0: never) the host waits for the device and raises if a
+    chained launch has given up since the last look, instead of computing on for the rest of the run.
     """
     hook = after_phase or (lambda i, name: None)
     table, row = swarm.exchange_table, swarm.exchange_table[swarm.rank]
+    on_gpu = getattr(getattr(swarm, "device", None), "type", None) == "cuda"
+
+    def stop_or_check(i):
+        if early_stopping and i % poll_every == 0:
+            return bool(int(swarm.control()[_lib.CTRL_STOP_ITER]))  # (control() looks at the chains too)
+        if on_gpu and check_every and i % check_every == 0:
+            check_chains(swarm.device)
+        return False
+
     if diagnostics and getattr(swarm, "table_positions", False):
         moved = summed = 0  # last iteration whose move is done / whose sums wait in the records for an exchange
         for i in range(first, first + count):
@@ -690,7 +749,7 @@ def sharded_iterations(swarm, comm, first, count, spec, w_cogn, w_soci, schedule
             swarm.after_exchange(i, schedule_inertia, early_stopping, tolerance, w_cogn, w_soci, seed, summed)
             hook(i, "move")
             summed, moved = moved, i
-            if early_stopping and i % poll_every == 0 and int(swarm.control()[_lib.CTRL_STOP_ITER]):
+            if stop_or_check(i):
                 break
         if moved:
             comm.all_gather(table, row)
@@ -716,7 +775,7 @@ def sharded_iterations(swarm, comm, first, count, spec, w_cogn, w_soci, schedule
         hook(i, "move")
         if diagnostics:
             pending = (i, comm.start_gather_positions(swarm.pos, swarm.n_global))
-        if early_stopping and i % poll_every == 0 and int(swarm.control()[_lib.CTRL_STOP_ITER]):
+        if stop_or_check(i):
             break
     if pending is not None:
         swarm.distance_part(pending[0], pending[1].wait())

@@ -22,4 +22,4 @@ def vq_st(inputs, codebook):
     return codes.view_as(inputs), idx.reshape(-1)
 
 
-__all__ = [vq, vq_st]
+__all__ = ["vq", "vq_st"]

@@ -96,7 +96,9 @@ class Discovery:
         assert torch.max(img01) <= 1.0
         assert torch.min(img01) >= 0.0
         s = img.shape[-1]
-        return fit.cpu().numpy(), img01.reshape(-1, 1, s, s).clone(), img.reshape(-1, 1, s, s).clone()
+        fit = fit.cpu().numpy()
+        engine.check_chains(self.device)  # (the copy above has synchronised)
+        return fit, img01.reshape(-1, 1, s, s).clone(), img.reshape(-1, 1, s, s).clone()
 
     def fitness_pso_inverter(self, dim_space, pos, img, eps=0.1, w_ass=1.0, w_rec=1.0):
         z = self._latents(dim_space, pos)
@@ -106,7 +108,9 @@ class Discovery:
         s = ev.gen.side
         target = img.to(self.device, torch.float32).reshape(-1, s, s).contiguous()
         fit, img01, img_rec = ev.fitness(z, self.fitness_spec(eps, w_ass, w_rec), target=target)
-        return fit.cpu().numpy(), img01.reshape(-1, 1, s, s).clone(), img_rec.reshape(-1, 1, s, s).clone()
+        fit = fit.cpu().numpy()
+        engine.check_chains(self.device)
+        return fit, img01.reshape(-1, 1, s, s).clone(), img_rec.reshape(-1, 1, s, s).clone()
 
     # ---- batched form used by the swarm loop
     def fitness_batch(self, pos, eps=0.1, target=None, w_ass=1.0, w_rec=1.0):

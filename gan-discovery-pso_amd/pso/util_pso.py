@@ -67,10 +67,14 @@ class Swarm:
         self.record_fitness = False     # keep every iteration's fitness vector in results['fitness']
         self.device_rng_seed = None     # set to an int to draw r1, r2 on the device (Philox) instead of numpy
         self.verbose = True
+        self.comm = None                # an engine.TorchComm (or an object with its methods): shard the particles over its ranks
+        self.rng = None                 # a numpy RandomState to draw from instead of numpy's global stream
         self.results = None
 
     # ------------------------------------------------------------------ helpers
     def _comm(self):
+        if self.comm is not None:  # set explicitly: also a group of one rank goes through the sharded loop
+            return self.comm
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             return engine.TorchComm()
@@ -101,27 +105,30 @@ class Swarm:
     # ------------------------------------------------------------------ the loop
     def optimize(self, schedule_inertia=False, early_stopping=True, ood_patient=None, encoder=None):
         n, d, t = self.num_particles, self.dim_space, self.n_iterations
+        rng = self.rng if self.rng is not None else np.random
         targets = None
         if ood_patient is not None:
             latents, targets = self._encode_targets(ood_patient, encoder)
             n = latents.shape[0]
             pos0 = latents.astype(np.float64)
-            vel0 = (np.random.randn(n, d) - 0.5) / 10
+            vel0 = (rng.randn(n, d) - 0.5) / 10
         else:
-            r = np.random.randn(n, 2, d)  # == N x (randn(d) for pos, randn(d) for vel)
+            r = rng.randn(n, 2, d)  # == N x (randn(d) for pos, randn(d) for vel)
             pos0, vel0 = r[:, 0, :].copy(), (r[:, 1, :] - 0.5) / 10
         rand = None
         if self.device_rng_seed is None:
-            rng_state = np.random.get_state()
-            rand = np.random.random((t, n, 2))  # (r1, r2) per particle per iteration, reference order
+            rng_state = rng.get_state()
+            rand = rng.random_sample((t, n, 2))  # (r1, r2) per particle per iteration, reference order
 
         comm = self._comm()
         rank, world = (comm.rank, comm.world) if comm else (0, 1)
         lo, hi = engine.shard_bounds(n, world, rank)
         ev = self.discovery.evaluator()
         spec = self.discovery.fitness_spec()
+        # ranks of equal size: the positions travel behind the candidate records, one collective per iteration
         sw = engine.HipSwarm(ev, hi - lo, d, t, first_index=lo, n_ranks=world, rank=rank, n_global=n,
-                             history=self.record_history, diagnostics=self.diagnostics, record_fitness=self.record_fitness)
+                             history=self.record_history, diagnostics=self.diagnostics, record_fitness=self.record_fitness,
+                             table_positions=comm is not None and self.diagnostics and n % world == 0)
         sw.f32_first_move = ood_patient is not None
         sw.load(pos0[lo:hi], vel0[lo:hi], self.w_inertia, rand=None if rand is None else rand[:, lo:hi, :],
                 target=None if targets is None else targets[lo:hi])
@@ -137,8 +144,8 @@ class Swarm:
         iters = res["iters"]
         if rand is not None and iters < t:
             # leave numpy's stream where the reference would have left it
-            np.random.set_state(rng_state)
-            np.random.random((iters, n, 2))
+            rng.set_state(rng_state)
+            rng.random_sample((iters, n, 2))
         return self._finish(res, n, targets, sw.pos if comm is None else None)
 
     def _finish(self, res, n, targets, device_pos):
@@ -246,8 +253,8 @@ def optimize_swarms(swarms, schedule_inertia=False, early_stopping=True):
     if len({(sp.mode, sp.threshold, sp.eps) for sp in specs}) != 1:
         raise ValueError("optimize_swarms: the swarms must share control_pso_fitness, threshold and eps")
     batch = engine.HipSwarmBatch(ev, [sw.num_particles for sw in swarms], first.dim_space, [sw.n_iterations for sw in swarms],
-                                 history=all(sw.record_history for sw in swarms), diagnostics=all(sw.diagnostics for sw in swarms),
-                                 record_fitness=any(sw.record_fitness for sw in swarms))
+                                 history=[sw.record_history for sw in swarms], diagnostics=[sw.diagnostics for sw in swarms],
+                                 record_fitness=[sw.record_fitness for sw in swarms])
     params = []
     for sw, hs, (pos0, vel0, rand) in zip(swarms, batch.swarms, draws):
         hs.load(pos0, vel0, sw.w_inertia, rand=rand)

@@ -26,7 +26,9 @@
 extern "C" {
 #endif
 
-/* 2: gdpso_swarm gained cand_stride and the candidate records two distance-sum slots (GDPSO_CAND_DOUBLES) */
+/* 2: gdpso_swarm gained cand_stride and the candidate records two distance-sum slots (GDPSO_CAND_DOUBLES);
+ *    gdpso_swarm_scratch_bytes(n) grew about eightfold (one partial record per 32 particles instead of
+ *    per 256): size the scratch buffer with the function, never with a constant from an older build */
 #define GDPSO_ABI_VERSION 2
 
 #define GDPSO_OK 0
@@ -392,6 +394,18 @@ unsigned gdpso_fast_div_check(unsigned n, unsigned d);
  * Chains run on a device only while the library has seen a single stream there;
  * every call also forgets the streams seen so far. */
 int gdpso_chain_debug(int enabled, unsigned drop_xcc_mask, int teams);
+
+/* No counterpart in the reference (one process, one batch size): options of the launch plans made from
+ * now on (a handle keeps the plans it has already made, one per batch size it has seen).
+ * plan_images > 0: tile shapes and split-K counts are chosen as if every batch held that many images,
+ * whatever its size (0: every batch by its own size, the default).  The tile shape fixes the order in
+ * which a row's partial sums over K are added, so with one plan_images an image gets the same bits in
+ * any batch: a swarm sharded over ranks (each evaluating its block of particles) then reproduces the
+ * unsharded run bit for bit when both plan for the same size, e.g. the ranks' block size.
+ * splitk = 0: K is never split over workgroups (a chained launch never splits it; with 0 the launches
+ * per layer add in the chain's order at every batch size).  Environment: GDPSO_PLAN_IMAGES,
+ * GDPSO_PLAN_SPLITK give the initial values. */
+int gdpso_plan_options(int plan_images, int splitk);
 
 /* No counterpart in the reference: the tile shape (64, 32 or 16, as in gdpso_conv_probe) a convolution layer
  * would run with as a step of a chained launch over n_images images with `teams` (1 or 2) teams per XCD, or 0

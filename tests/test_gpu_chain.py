@@ -82,6 +82,29 @@ def test_chain_matches_per_layer_launches(eng, lib, synth, model, n, side, exact
     assert _aborts(lib) == before
 
 
+@pytest.mark.parametrize("n,side,drop,teams", [(57, 64, 0, 1), (57, 64, 0xF0, 1), (57, 64, 0, 2), (9, 64, 0, 1), (41, 64, 0x7F, 1), (121, 28, 0, 1),
+                                               (57, 64, 0xFE, 2)])
+def test_chain_uneven_batches_on_larger_maps(eng, lib, synth, n, side, drop, teams):
+    """Batches that do not divide by the number of shares, on maps large enough for a share to have MORE tiles
+    in a step than its team has members: a member's first tile of a step may then lie in the empty tail of one
+    border class (past the last share's rows) while a later tile of the same member is a real one in the next
+    class -- the step's wait must have been taken by then.  57 images of 64x64: 8 a share and 1 in the last, 84
+    tiles of 32x32 in the 3x3 layers of the second stage for 64 members.  With XCDs standing aside the remaining
+    ones walk several shares each.  K is never split in either path here, so both add in the same order."""
+    before = _aborts(lib)
+    eng.plan_options(plan_images=0, splitk=False)
+    try:
+        plain, _ = _logits(eng, lib, synth, "ResNet50", n, side, chained=False)
+        chained, _ = _logits(eng, lib, synth, "ResNet50", n, side, chained=True, drop=drop, teams=teams)
+    finally:
+        eng.plan_options(plan_images=0, splitk=True)
+    if teams == 1:
+        np.testing.assert_array_equal(chained, plain)
+    else:  # two teams: shares of a sixteenth, some layers on smaller tiles whose K parts add in another order
+        np.testing.assert_allclose(chained, plain, rtol=1e-4, atol=2e-4)
+    assert _aborts(lib) == before
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 def test_chain_16bit_matches_per_layer_launches(eng, lib, synth, dtype):
     """16-bit storage: the chained launch runs the same tiles in the same order as the launches per layer."""

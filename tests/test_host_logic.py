@@ -254,6 +254,13 @@ def test_bench_launches_its_own_ranks():
     assert len(lines) == 1, res.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["dry_run"] is True and out["steps"] == 3
+    # the keys a real N > 1 line carries: per-phase times with the collective, the spread over the ranks
+    assert set(out["phases"]) >= {"generator_ms", "assessor_ms", "pso_update_and_diagnostic_ms", "collective_ms", "how"}
+    assert out["phases"]["collective_ms"] is not None and out["phases"]["collective_ms"] >= 0
+    assert out["ranks"]["n_ranks_seen"] == 2
+    assert out["ranks"]["ms_per_step_max"] == 2.0 and out["ranks"]["ms_per_step_min"] == 1.0 and out["ms_per_step"] == 2.0
+    for key in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in out
 
 
 def test_evaluator_cache_key_follows_the_weights(synth):
