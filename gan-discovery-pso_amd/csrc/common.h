@@ -115,6 +115,10 @@ struct ConvLayer {
     ConvPhase phase[MAX_PHASES];
     int dtype;           // DType of the weights at `wt` and of the activations the layer reads and writes
     const void *wt;      // device, elements of `dtype`
+    // The same weights once more in chunk-major order, for the tile shapes whose waves load their B fragments
+    // straight from global memory: every [cout][wstride] matrix as [cout / 32][wstride / VEC][32][VEC], VEC = the
+    // elements of a 16-byte chunk (null when cout is not a multiple of 32 or a row not a whole number of chunks).
+    const void *wtq;
     const float *scale;  // device [cout] (never null)
     const float *shift;  // device [cout]
     const int *table;    // device [nphase][PHASE_HDR + MAX_TAPS], see upload_conv
@@ -180,6 +184,10 @@ struct DeviceArena {
 // table; fills the device pointers and L.dtype.
 int upload_conv(DeviceArena &arena, ConvLayer &L, const std::vector<float> &packed,
                 const std::vector<float> &scale, const std::vector<float> &shift, int dtype = DT_F32);
+
+// The PHASE_HDR + 1 ints a workgroup reads about its phase: the header of the phase's row of the device
+// table (upload_conv) followed by the first packed tap.
+void conv_phase_header(const ConvPhase &P, int *out);
 
 // fp32 -> bf16 / fp16 bit patterns, round-to-nearest-even (host).
 uint16_t f32_to_bf16_bits(float v);

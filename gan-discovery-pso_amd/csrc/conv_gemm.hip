@@ -41,6 +41,13 @@
 
 #include "common.h"
 
+#ifndef GDPSO_BDIRECT
+#define GDPSO_BDIRECT 1  // 0: weights staged through LDS in every tile shape (A/B builds)
+#endif
+#ifndef GDPSO_PF
+#define GDPSO_PF 2  // K-tiles the one-block-per-wave tile shapes keep in flight in registers (2 or 3)
+#endif
+
 namespace gdpso {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -60,6 +67,7 @@ constexpr int PHASE_TABLE_INTS = PHASE_HDR + MAX_TAPS;  // header (see upload_co
 struct ConvKArgs {
     const void *in;    // NHWC activations, elements of the instantiation's type
     const void *wt;    // packed weights, same type
+    const void *wtq;   // the same weights in chunk-major layout (see BD in conv_tile), or null
     const float *scale;
     const float *shift;
     const void *res;   // residual, same type as the activations, or null
@@ -418,6 +426,16 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
     constexpr int WM = KW == 1 ? BM / 64 : 1, WN = KW == 1 ? BN / 64 : 1;  // 32x32 MFMA blocks per wave
     constexpr int RP = 256 / (BKT / VEC);      // rows covered by one loader pass
     constexpr int PA = BM / RP, PB = BN / RP;  // loader passes
+    // BD: the B operand (weights) never passes through LDS.  In every tile shape with one MFMA block per wave a
+    // wave's B fragments are its own (the 32 columns of its block over its part of the K-tile), or shared with
+    // one other wave only (64x64), so LDS staging buys no reuse and costs the staging stores, which are what
+    // bounds a K loop that is alone on its CU (ds_write_b128 moves its VGPRs to the LDS at ~13 cycles a wave
+    // instruction on a path the four SIMDs share: measured, 16 K-steps of the 32x32 tile take 12.6 us with the
+    // stores and 8.3 us without, against 7.7 us of MFMA time).  The weights are kept a second time in
+    // chunk-major order, [32-column block][16-byte chunk of K][32 columns][VEC elements], in which the 64 lanes
+    // of a wave's fragment load (lane = column, lane half = odd / even chunk) read 1 KiB contiguously, and go
+    // from global memory straight into the registers the MFMAs read.
+    constexpr bool BD = GDPSO_BDIRECT && WM * WN == 1 && KW > 1;
     constexpr int LDS_FLOATS = 2 * (BM + BN) * LDA * (int)sizeof(E) / 4;
     static_assert(LDS_FLOATS >= BM * (BN + 4) + 4, "the output tile is staged in the operand buffers");
     E *sA = (E *)lds;
@@ -446,7 +464,7 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
     // scalar-load round trips of ~0.25 us each ahead of the first operand load.
 #define GDPSO_W(I) "s"(a.phase_word[I])
     static_assert(MAX_PHASES == 16, "the operand list names 16 phases");
-    asm volatile("" ::"s"(a.in), "s"(a.wt), "s"(a.table), "s"(a.n_images), "s"(a.hin), "s"(a.win), "s"(a.cin),
+    asm volatile("" ::"s"(a.in), "s"(a.wt), "s"(a.wtq), "s"(a.table), "s"(a.n_images), "s"(a.hin), "s"(a.win), "s"(a.cin),
                  "s"(a.in_stride), "s"(a.splits), "s"(a.tiles_n), "s"(a.per_xcd), "s"(a.snake), "s"(a.tiles_n_mul),
                  "s"(a.tiles_n_shift), GDPSO_W(0), GDPSO_W(1), GDPSO_W(2), GDPSO_W(3), GDPSO_W(4), GDPSO_W(5), GDPSO_W(6),
                  GDPSO_W(7), GDPSO_W(8), GDPSO_W(9), GDPSO_W(10), GDPSO_W(11), GDPSO_W(12), GDPSO_W(13), GDPSO_W(14),
@@ -486,19 +504,22 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
     // memory may have changed, and falls back to vector loads).
     typedef const __attribute__((address_space(4))) int *const_int_ptr;
     const const_int_ptr tab = (const_int_ptr)(uintptr_t)(a.table + ph * PHASE_TABLE_INTS);
-    const int ntaps = tab[0];
-    const int tap0_packed = tab[PHASE_HDR];  // read with the header: one scalar-load round trip fewer
+    int hdr[PHASE_HDR + 1];
+#pragma unroll
+    for (int i = 0; i <= PHASE_HDR; ++i) hdr[i] = tab[i];  // (the first tap comes with the header: one scalar-load round trip fewer)
+    const int ntaps = hdr[0];
+    const int tap0_packed = hdr[PHASE_HDR];  // read with the header: one scalar-load round trip fewer
     PhaseInfo P;
-    P.off_y = tab[1];
-    P.off_x = tab[2];
-    P.hm = tab[4];
-    P.wm = tab[5];
+    P.off_y = hdr[1];
+    P.off_x = hdr[2];
+    P.hm = hdr[4];
+    P.wm = hdr[5];
     P.M = a.n_images * P.hm * P.wm;
-    P.hw_mul = (unsigned)tab[9];
-    P.wm_mul = (unsigned)tab[10];
-    P.hw_shift = (unsigned)tab[11] & 0xff;
-    P.wm_shift = ((unsigned)tab[11] >> 8) & 0xff;
-    const int in_y0 = tab[6], in_x0 = tab[7], wstride = tab[8];
+    P.hw_mul = (unsigned)hdr[9];
+    P.wm_mul = (unsigned)hdr[10];
+    P.hw_shift = (unsigned)hdr[11] & 0xff;
+    P.wm_shift = ((unsigned)hdr[11] >> 8) & 0xff;
+    const int in_y0 = hdr[6], in_x0 = hdr[7], wstride = hdr[8];
     if constexpr (CHAIN) {
         // the share's rows of this phase: tiles start at its first row, the last one may be partly (or, in
         // the last shares of a batch that does not divide by the number of shares, wholly) past its end
@@ -517,7 +538,7 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
     asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(wstride), "s"(ntaps) : "memory");  // the phase header has arrived
     GDPSO_STAMP(8)
 #endif
-    const E *wt = (const E *)a.wt + tab[3];
+    const E *wt = (const E *)a.wt + hdr[3];
     const int ktot = ntaps * a.cin;
     // this phase's K range per split (the divide only where K is split at all)
     const int ksplit = a.splits == 1 ? ktot : ((ktot / BKT + a.splits - 1) / a.splits) * BKT;
@@ -556,6 +577,12 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
         rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, a.n_images * a.hin * a.win * a.cin * (int)sizeof(E), 0x00020000);
 #pragma unroll
     for (int p = 0; p < PB; ++p) brow[p] = wt + ((n0 + lrow + RP * p) * wstride + lcol);  // 32-bit offsets: see conv_args
+    // BD: this lane's chunk 0 of the K-tile at weight-row position 0: column block (n0 + wc * BN / 2) / 32, column
+    // l31, chunk kh * 8 + half of the K-tile; a chunk of K is 32 * VEC elements further on, a lane's four
+    // fragments of a K-tile (chunks 2 g + half) 64 * VEC elements apart
+    const E *bq0 = nullptr, *bqp = nullptr;
+    if constexpr (BD)
+        bq0 = (const E *)a.wtq + hdr[3] + ((size_t)((n0 + wc * (BN / 2)) >> 5) * (wstride / VEC) * 32 + l31 + (kh * 8 + half) * 32) * VEC;
     int tap = a.splits == 1 ? 0 : kbeg / a.cin, ci0 = kbeg - tap * a.cin;
 #define GDPSO_SET_TAP(CI, PACKED)                                                                               \
     {                                                                                                           \
@@ -571,7 +598,10 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
                 aptr[p] = ok ? in + ((a_img[p] + iy * a.win + ix) * a.cin + (CI) + lcol)                        \
                              : (const E *)g_zero_page + (CI) + lcol;                                            \
         }                                                                                                       \
-        _Pragma("unroll") for (int p = 0; p < PB; ++p) bptr[p] = brow[p] + wk_;                                 \
+        if constexpr (BD)                                                                                       \
+            bqp = bq0 + wk_ * 32;                                                                               \
+        else                                                                                                    \
+            _Pragma("unroll") for (int p = 0; p < PB; ++p) bptr[p] = brow[p] + wk_;                             \
     }
     // Prefetch registers for the next K-tile.  Native vector types over fully unrolled loops:
     // with HIP's float4 struct these arrays were not promoted to registers (they went to
@@ -580,8 +610,9 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
     // cover a load's latency: they keep TWO K-tiles in flight, in two register sets that are
     // always named by literal index (a run-time index would put the arrays in scratch).
     constexpr bool PF2 = WM * WN == 1;
-    constexpr int NSET = PF2 ? 2 : 1;
-    f32x4 ra[NSET][PA], rb[NSET][PB];
+    constexpr int NSET = PF2 ? GDPSO_PF : 1;  // K-tiles in flight in registers
+    static_assert(GDPSO_PF == 2 || GDPSO_PF == 3, "two or three register sets");
+    f32x4 ra[NSET][PA], rb[NSET][BD ? 4 : PB];  // BD: rb[set][g] is the wave's B fragment of MFMA group g
     // A K-tile's loads (straight-line, so that a K-step can interleave them with its MFMAs) and,
     // separately, the move of the gather pointers to the next K-tile (which branches at a tap change).
 #define GDPSO_GISSUE_A(S)                                                                                       \
@@ -595,8 +626,14 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
     }
 #define GDPSO_GISSUE_B(S)                                                                                       \
     {                                                                                                           \
-        _Pragma("unroll") for (int p = 0; p < PB; ++p) rb[S][p] = *(global_f32x4_ptr)bptr[p];                    \
+        if constexpr (BD) {                                                                                     \
+            _Pragma("unroll") for (int g = 0; g < 4; ++g) rb[S][g] = *(global_f32x4_ptr)(bqp + g * 64 * VEC);    \
+        } else {                                                                                                \
+            _Pragma("unroll") for (int p = 0; p < PB; ++p) rb[S][p] = *(global_f32x4_ptr)bptr[p];                \
+        }                                                                                                       \
     }
+    // BD: fragment G of the K-tile two ahead, into the registers the MFMAs of group G have just read
+#define GDPSO_GISSUE_BG(S, G) rb[S][G] = *(global_f32x4_ptr)(bqp + (G) * 64 * VEC);
 #define GDPSO_GISSUE(S)                                                                                         \
     {                                                                                                           \
         GDPSO_GISSUE_A(S)                                                                                       \
@@ -610,7 +647,10 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
             else                                                                                                \
                 aptr[p] += BKT;                                                                                 \
         }                                                                                                       \
-        _Pragma("unroll") for (int p = 0; p < PB; ++p) bptr[p] += BKT;                                          \
+        if constexpr (BD)                                                                                       \
+            bqp += BKT * 32;                                                                                    \
+        else                                                                                                    \
+            _Pragma("unroll") for (int p = 0; p < PB; ++p) bptr[p] += BKT;                                      \
         ci0 += BKT;                                                                                             \
         if (ci0 == a.cin) {                                                                                     \
             ci0 = 0;                                                                                            \
@@ -626,14 +666,18 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
     {                                                                                                           \
         _Pragma("unroll") for (int p = 0; p < PA; ++p)                                                          \
             *(f32x4 *)(void *)&sA[(BUF) * BM * LDA + (lrow + RP * p) * LDA + lcol] = ra[S][p];                  \
-        _Pragma("unroll") for (int p = 0; p < PB; ++p)                                                          \
-            *(f32x4 *)(void *)&sB[(BUF) * BN * LDA + (lrow + RP * p) * LDA + lcol] = rb[S][p];                  \
+        if constexpr (!BD) {                                                                                    \
+            _Pragma("unroll") for (int p = 0; p < PB; ++p)                                                      \
+                *(f32x4 *)(void *)&sB[(BUF) * BN * LDA + (lrow + RP * p) * LDA + lcol] = rb[S][p];              \
+        }                                                                                                       \
     }
     // Operand fragments of MFMA group G (two 16-byte vectors of k: one per lane half) into register set SET.
 #define GDPSO_LOADFRAG(SET, G)                                                                                  \
     {                                                                                                           \
         _Pragma("unroll") for (int i = 0; i < WM; ++i) av[SET][i] = *(const f32x4 *)(const void *)(pa + i * 32 * LDA + (G) * 2 * VEC); \
-        _Pragma("unroll") for (int j = 0; j < WN; ++j) bv[SET][j] = *(const f32x4 *)(const void *)(pb + j * 32 * LDA + (G) * 2 * VEC); \
+        if constexpr (!BD) {                                                                                    \
+            _Pragma("unroll") for (int j = 0; j < WN; ++j) bv[SET][j] = *(const f32x4 *)(const void *)(pb + j * 32 * LDA + (G) * 2 * VEC); \
+        }                                                                                                       \
     }
 
     f32x16 acc[WM][WN];
@@ -668,6 +712,9 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
         // CU's 64 B/clk load path with it and delay the first MFMA
         if constexpr (PF2) {
             if (nk > 1) GDPSO_GLOAD(1)
+            if constexpr (NSET == 3) {
+                if (nk > 2) GDPSO_GLOAD(2)
+            }
         }
     }
     // What the epilogue reads from the kernel arguments is demanded here, so that it arrives during
@@ -703,9 +750,11 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
     if ((N) > 0) __builtin_amdgcn_sched_group_barrier(MASK, (N) > 0 ? (N) : 1, 0);
 #define GDPSO_SGB4(MA, NA, MB, NB) \
     GDPSO_SGB(MA, NA) GDPSO_SGB(MB, NB) GDPSO_SGB(MA, NA) GDPSO_SGB(MB, NB) GDPSO_SGB(MA, NA) GDPSO_SGB(MB, NB) GDPSO_SGB(MA, NA) GDPSO_SGB(MB, NB)
-#define GDPSO_KSTEP(LOAD, LS, MORE, SS)                                                                         \
+#define GDPSO_KSTEP(LOAD, LS, MORE, SS, BS)                                                                     \
     {                                                                                                           \
-        if ((LOAD) && GDPSO_DBG(2)) GDPSO_GISSUE(LS)                                                            \
+        if ((LOAD) && GDPSO_DBG(2)) {                                                                           \
+            if constexpr (BD) GDPSO_GISSUE_A(LS) else GDPSO_GISSUE(LS)                                          \
+        }                                                                                                       \
         const E *pa = sA + buf * BM * LDA + (wr * (BM / 2) + l31) * LDA + half * VEC + kh * 8 * VEC;           \
         const E *pb = sB + buf * BN * LDA + (wc * (BN / 2) + l31) * LDA + half * VEC + kh * 8 * VEC;           \
         f32x4 av[2][WM], bv[2][WN];                                                                             \
@@ -713,7 +762,17 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
         _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                         \
             if (g < 3) GDPSO_LOADFRAG((g + 1) & 1, g + 1)                                                       \
             if (g == 3 && (MORE) && GDPSO_DBG(4)) GDPSO_SSTORE(buf ^ 1, SS)                                     \
-            if constexpr (F32) {                                                                                \
+            if constexpr (BD) {                                                                                 \
+                /* B: fragment g of this K-tile straight from the registers its load filled (set BS) */        \
+                if constexpr (F32) {                                                                            \
+                    _Pragma("unroll") for (int s = 0; s < 4; ++s)                                               \
+                        if (GDPSO_DBG(1))                                                                       \
+                            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1][0][s], rb[BS][g][s], acc[0][0], 0, 0, 0); \
+                } else {                                                                                        \
+                    acc[0][0] = mfma16<E>(av[g & 1][0], rb[BS][g], acc[0][0]);                                  \
+                }                                                                                               \
+                if ((LOAD) && GDPSO_DBG(2)) GDPSO_GISSUE_BG(BS, g)                                              \
+            } else if constexpr (F32) {                                                                         \
                 _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                   \
                     _Pragma("unroll") for (int i = 0; i < WM; ++i)                                              \
                         _Pragma("unroll") for (int j = 0; j < WN; ++j)                                          \
@@ -727,6 +786,24 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
         }                                                                                                       \
         if constexpr (!F32) {                                                                                   \
             /* 16-bit: a K-step is 4 (or 16) short MFMAs; the compiler's own schedule is kept */                 \
+        } else if constexpr (BD) {                                                                              \
+            /* one A fragment read per MFMA group, the A loads of the K-tile two ahead behind MFMAs 1-3, each  */ \
+            /* B fragment reloaded behind the group that has just read it, the A stores behind MFMAs 9-12      */ \
+            constexpr int NA = (LOAD) ? PA : 0, NB = (LOAD) ? 1 : 0, NW = (MORE) ? PA : 0;                      \
+            GDPSO_SGB(0x100, 1)                                                                                 \
+            GDPSO_SGB(0x008, 1) GDPSO_SGB(0x100, 1)                                                             \
+            GDPSO_SGB(0x008, 1) GDPSO_SGB(0x020, (NA + 2) / 3)                                                  \
+            GDPSO_SGB(0x008, 1) GDPSO_SGB(0x020, (NA + 1) / 3)                                                  \
+            GDPSO_SGB(0x008, 1) GDPSO_SGB(0x020, NA / 3)                                                        \
+            GDPSO_SGB(0x008, 1) GDPSO_SGB(0x100, 1) GDPSO_SGB(0x020, NB)                                        \
+            GDPSO_SGB(0x008, 3)                                                                                 \
+            GDPSO_SGB(0x008, 1) GDPSO_SGB(0x100, 1) GDPSO_SGB(0x020, NB)                                        \
+            GDPSO_SGB(0x008, 1) GDPSO_SGB(0x200, (NW + 3) / 4)                                                  \
+            GDPSO_SGB(0x008, 1) GDPSO_SGB(0x200, (NW + 2) / 4)                                                  \
+            GDPSO_SGB(0x008, 1) GDPSO_SGB(0x200, (NW + 1) / 4)                                                  \
+            GDPSO_SGB(0x008, 1) GDPSO_SGB(0x200, NW / 4) GDPSO_SGB(0x020, NB)                                   \
+            GDPSO_SGB(0x008, 3)                                                                                 \
+            GDPSO_SGB(0x020, NB)                                                                                \
         } else if constexpr (WM * WN == 1) {                                                                    \
             constexpr int NV = (LOAD) ? PA + PB : 0, NW = (MORE) ? PA + PB : 0;                                 \
             GDPSO_SGB(0x100, 2)                                                                                 \
@@ -761,28 +838,52 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
         if (LOAD) GDPSO_GADVANCE()                                                                              \
     }
     int buf = 0;
-    if constexpr (PF2) {
+    if constexpr (PF2 && NSET == 3) {
+        // K-tile t travels through register set t % 3: step t issues the loads of tile t + 3 into the set that
+        // tile t left (its A half went to LDS a step ago, its B fragments are reloaded group by group as the
+        // MFMAs read them), and moves the A half of tile t + 1, loaded two steps ago, into LDS.
+        int t = 0;
+        for (; t + 5 < nk; t += 3) {
+            GDPSO_KSTEP(true, 0, true, 1, 0)
+            GDPSO_KSTEP(true, 1, true, 2, 1)
+            GDPSO_KSTEP(true, 2, true, 0, 2)
+        }
+        const int left = nk - t;  // 0 (empty K range) to 5; t is a multiple of 3
+#define GDPSO_TAIL(I)                                                                         \
+    if (left > (I)) {                                                                         \
+        if ((I) + 3 < left) GDPSO_KSTEP(true, (I) % 3, true, ((I) + 1) % 3, (I) % 3)           \
+        else if ((I) + 1 < left) GDPSO_KSTEP(false, 0, true, ((I) + 1) % 3, (I) % 3)           \
+        else GDPSO_KSTEP(false, 0, false, 0, (I) % 3)                                         \
+    }
+        GDPSO_TAIL(0)
+        GDPSO_TAIL(1)
+        GDPSO_TAIL(2)
+        GDPSO_TAIL(3)
+        GDPSO_TAIL(4)
+#undef GDPSO_TAIL
+    } else if constexpr (PF2) {
         // K-tile t travels through register set t & 1: step t issues the loads of tile t + 2 into
         // the set that tile t left, and moves tile t + 1 (loaded a whole step ago) into LDS.
+        // (BD: the B half of a set is not moved anywhere: step t's MFMAs read it where it is, last argument.)
         int t = 0;
         for (; t + 3 < nk; t += 2) {
-            GDPSO_KSTEP(true, 0, true, 1)
-            GDPSO_KSTEP(true, 1, true, 0)
+            GDPSO_KSTEP(true, 0, true, 1, 0)
+            GDPSO_KSTEP(true, 1, true, 0, 1)
         }
         const int left = nk - t;  // 0 (empty K range), 1, 2 or 3; t is even
         if (left == 3) {
-            GDPSO_KSTEP(true, 0, true, 1)
-            GDPSO_KSTEP(false, 0, true, 0)
-            GDPSO_KSTEP(false, 0, false, 0)
+            GDPSO_KSTEP(true, 0, true, 1, 0)
+            GDPSO_KSTEP(false, 0, true, 0, 1)
+            GDPSO_KSTEP(false, 0, false, 0, 0)
         } else if (left == 2) {
-            GDPSO_KSTEP(false, 0, true, 1)
-            GDPSO_KSTEP(false, 0, false, 0)
+            GDPSO_KSTEP(false, 0, true, 1, 0)
+            GDPSO_KSTEP(false, 0, false, 0, 1)
         } else if (left == 1) {
-            GDPSO_KSTEP(false, 0, false, 0)
+            GDPSO_KSTEP(false, 0, false, 0, 0)
         }
     } else {
-        for (int t = 0; t + 1 < nk; ++t) GDPSO_KSTEP(true, 0, true, 0)
-        if (nk > 0) GDPSO_KSTEP(false, 0, false, 0)
+        for (int t = 0; t + 1 < nk; ++t) GDPSO_KSTEP(true, 0, true, 0, 0)
+        if (nk > 0) GDPSO_KSTEP(false, 0, false, 0, 0)
     }
 #undef GDPSO_KSTEP
 #undef GDPSO_SGB
@@ -790,6 +891,7 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
 #undef GDPSO_GISSUE
 #undef GDPSO_GISSUE_A
 #undef GDPSO_GISSUE_B
+#undef GDPSO_GISSUE_BG
 #undef GDPSO_GADVANCE
 #undef GDPSO_DBG
 #undef GDPSO_SET_TAP
@@ -1298,7 +1400,7 @@ int conv_splitk_prepare(hipStream_t stream, float *splitk_ws) {
 static int conv_args(const ConvLayer &L, int n_images, const void *in, const void *res, void *out, float *splitk_ws,
                      ConvKArgs &a, long *grid_x, bool *fused_reduce, int nshare = 0) {
     if (!dtype_ok(L.dtype)) return fail(GDPSO_ERR_ARG, "conv: unknown element type");
-    a.in = in; a.wt = L.wt; a.scale = L.scale; a.shift = L.shift; a.res = res; a.out = out;
+    a.in = in; a.wt = L.wt; a.wtq = L.wtq; a.scale = L.scale; a.shift = L.shift; a.res = res; a.out = out;
     const long tiles_m = m_tiles(L, n_images, L.tile);
     const long tiles_total = tiles_m * (L.cout / tile_bn(L.tile));
     a.table = L.table;
@@ -1345,6 +1447,7 @@ static int conv_args(const ConvLayer &L, int n_images, const void *in, const voi
     if ((long)n_images * L.hin * L.win * L.cin * 4 >= (1L << 31)) return fail(GDPSO_ERR_ARG, "conv: input larger than 2 GiB");
     if ((long)L.weight_floats * 4 >= (1L << 31)) return fail(GDPSO_ERR_ARG, "conv: weights larger than 2 GiB");
     if (tiles_total >= (1L << 30) || (long)n_images * L.hout * L.wout >= (1L << 31)) return fail(GDPSO_ERR_ARG, "conv: too many rows");
+    if (GDPSO_BDIRECT && L.tile != 128 && !L.wtq) return fail(GDPSO_ERR_ARG, "conv: the layer has no chunk-major weights (cout must be a multiple of 32)");
     if (L.tile == 32 && L.cin % (2 * kq) != 0) return fail(GDPSO_ERR_ARG, "conv: the 32-row tile needs cin to be a multiple of 64 (fp32) or 128 (16-bit)");
     if (L.tile == TILE_32x32 && L.cin % (4 * kq) != 0) return fail(GDPSO_ERR_ARG, "conv: the 32x32 tile needs cin to be a multiple of 128 (fp32) or 256 (16-bit)");
     return GDPSO_OK;

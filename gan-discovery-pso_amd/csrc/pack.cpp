@@ -250,6 +250,27 @@ uint16_t f32_to_f16_bits(float v) {
 // Device table of a layer: per phase PHASE_HDR ints {ntaps, off_y, off_x, wt_offset, hm, wm,
 // in_y0, in_x0, wstride, mul(hm * wm), mul(wm), shift(hm * wm) | shift(wm) << 8} (mul / shift: FastDiv) followed by MAX_TAPS packed taps (dy & 0xff) | (dx & 0xff) << 8
 // | wtap << 16.
+static int packed_tap(const ConvPhase &P, int k) {
+    return ((int)P.dy[k] & 0xff) | (((int)P.dx[k] & 0xff) << 8) | ((int)P.wtap[k] << 16);
+}
+
+void conv_phase_header(const ConvPhase &P, int *t) {
+    t[0] = P.ntaps;
+    t[1] = P.off_y;
+    t[2] = P.off_x;
+    t[3] = (int)P.wt_offset;
+    t[4] = P.hm;
+    t[5] = P.wm;
+    t[6] = P.in_y0;
+    t[7] = P.in_x0;
+    t[8] = P.wstride;
+    const FastDiv dhw = fast_div_for((unsigned)(P.hm * P.wm)), dw = fast_div_for((unsigned)P.wm);
+    t[9] = (int)dhw.mul;
+    t[10] = (int)dw.mul;
+    t[11] = (int)(dhw.shift | (dw.shift << 8));
+    t[PHASE_HDR] = P.ntaps > 0 ? packed_tap(P, 0) : 0;
+}
+
 int upload_conv(DeviceArena &arena, ConvLayer &L, const std::vector<float> &packed,
                 const std::vector<float> &scale, const std::vector<float> &shift, int dtype) {
     L.dtype = dtype;
@@ -257,29 +278,41 @@ int upload_conv(DeviceArena &arena, ConvLayer &L, const std::vector<float> &pack
     for (int p = 0; p < L.nphase; ++p) {
         const ConvPhase &P = L.phase[p];
         int *t = table.data() + (size_t)p * (PHASE_HDR + MAX_TAPS);
-        t[0] = P.ntaps;
-        t[1] = P.off_y;
-        t[2] = P.off_x;
-        t[3] = (int)P.wt_offset;
-        t[4] = P.hm;
-        t[5] = P.wm;
-        t[6] = P.in_y0;
-        t[7] = P.in_x0;
-        t[8] = P.wstride;
-        const FastDiv dhw = fast_div_for((unsigned)(P.hm * P.wm)), dw = fast_div_for((unsigned)P.wm);
-        t[9] = (int)dhw.mul;
-        t[10] = (int)dw.mul;
-        t[11] = (int)(dhw.shift | (dw.shift << 8));
-        for (int k = 0; k < P.ntaps; ++k)
-            t[PHASE_HDR + k] = ((int)P.dy[k] & 0xff) | (((int)P.dx[k] & 0xff) << 8) | ((int)P.wtap[k] << 16);
+        conv_phase_header(P, t);
+        for (int k = 0; k < P.ntaps; ++k) t[PHASE_HDR + k] = packed_tap(P, k);
     }
     int rc;
+    // chunk-major copy: element (co, k) of the matrix at wt_offset goes to
+    // wt_offset + (((co / 32) * (wstride / vec) + k / vec) * 32 + co % 32) * vec + k % vec
+    const int vec = dtype == DT_F32 ? 4 : 8;
+    bool quad_ok = L.cout % 32 == 0;
+    for (int p = 0; p < L.nphase; ++p) quad_ok = quad_ok && L.phase[p].wstride % vec == 0;
+    std::vector<float> quad;
+    if (quad_ok) {
+        quad.assign(packed.size(), 0.f);
+        std::vector<long> done;
+        for (int p = 0; p < L.nphase; ++p) {
+            const long off = L.phase[p].wt_offset;
+            if (std::find(done.begin(), done.end(), off) != done.end()) continue;  // phases share matrices
+            done.push_back(off);
+            const size_t ws = (size_t)L.phase[p].wstride, cpr = ws / vec;
+            for (int co = 0; co < L.cout; ++co)
+                for (size_t k = 0; k < ws; ++k)
+                    quad[off + ((((size_t)co / 32) * cpr + k / vec) * 32 + co % 32) * vec + k % vec] = packed[off + (size_t)co * ws + k];
+        }
+    }
+    L.wtq = nullptr;
     if (dtype == DT_F32) {
         if ((rc = arena.upload(packed.data(), packed.size() * sizeof(float), &L.wt))) return rc;
+        if (quad_ok && (rc = arena.upload(quad.data(), quad.size() * sizeof(float), &L.wtq))) return rc;
     } else {
         std::vector<uint16_t> half(packed.size());
         for (size_t i = 0; i < packed.size(); ++i) half[i] = dtype == DT_BF16 ? f32_to_bf16_bits(packed[i]) : f32_to_f16_bits(packed[i]);
         if ((rc = arena.upload(half.data(), half.size() * sizeof(uint16_t), &L.wt))) return rc;
+        if (quad_ok) {
+            for (size_t i = 0; i < quad.size(); ++i) half[i] = dtype == DT_BF16 ? f32_to_bf16_bits(quad[i]) : f32_to_f16_bits(quad[i]);
+            if ((rc = arena.upload(half.data(), half.size() * sizeof(uint16_t), &L.wtq))) return rc;
+        }
     }
     if ((rc = arena.upload(scale, &L.scale))) return rc;
     if ((rc = arena.upload(shift, &L.shift))) return rc;

@@ -16,7 +16,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-LIB = os.path.join(HERE, "libgdpso_stamps.so")
+LIB = os.environ.get("GDPSO_STAMPS_LIB", os.path.join(HERE, "libgdpso_stamps.so"))  # (another diagnostic build of the library)
 CSRC = os.path.join(ROOT, "gan-discovery-pso_amd", "csrc")
 
 
