@@ -26,6 +26,58 @@ __global__ __launch_bounds__(256) void latent_prep_kernel(const void *__restrict
     out[e] = (E)v;
 }
 
+// First generator layer for short latents (z_dim <= GF_MAX_Z): ConvTranspose2d(Z -> 2F, k, s1, p0) on a 1x1
+// input + BatchNorm + ReLU (reference src/utils/util_dcgan.py:135,143-145) straight from the swarm's float64
+// positions.  With Z = 10 the layer is 10 multiply-adds per output: as a GEMM it needs its K padded to a
+// K-tile of 32 (two thirds of the matrix work on zeros) behind a kernel of its own that casts and pads the
+// latents.  Here a thread holds the Z weights of four consecutive outputs (position-major columns (ky, kx, co),
+// so the row it writes is the NHWC map) in registers and walks a few images; the latents of those images
+// come through LDS.  The sum runs over k in the order in which the matrix-core path adds the products of a
+// 32-wide K-tile (pairs (8 g + s, 8 g + 4 + s)), each step one fused multiply-add, so both paths round alike.
+constexpr int GF_MAX_Z = 16, GF_IMAGES = 4;
+template <typename E>
+__global__ __launch_bounds__(256) void gen_first_kernel(const void *__restrict__ z, int z_is_f64, int n, int zd, int ncol,
+                                                        const float *__restrict__ wt, const float *__restrict__ scale,
+                                                        const float *__restrict__ shift, E *__restrict__ out) {
+    __shared__ float s_z[GF_IMAGES * GF_MAX_Z];
+    const int tid = threadIdx.x, img0 = blockIdx.y * GF_IMAGES;
+    if (tid < GF_IMAGES * GF_MAX_Z) {
+        const int i = tid / GF_MAX_Z, k = tid % GF_MAX_Z, img = img0 + i;
+        float v = 0.f;
+        if (img < n && k < zd) v = z_is_f64 ? (float)((const double *)z)[(long)img * zd + k] : ((const float *)z)[(long)img * zd + k];
+        s_z[tid] = (float)(E)v;  // (16-bit storage: the latent rounded as the matrix-core path rounds its A operand)
+    }
+    __syncthreads();
+    const int col = (blockIdx.x * 256 + tid) * 4;
+    if (col >= ncol) return;
+    f32x4 w[GF_MAX_Z];
+#pragma unroll
+    for (int k = 0; k < GF_MAX_Z; ++k) {
+        w[k] = 0.f;
+        if (k < zd) w[k] = *(const f32x4 *)(wt + (size_t)k * ncol + col);
+    }
+    const f32x4 sc = *(const f32x4 *)(scale + col), sh = *(const f32x4 *)(shift + col);
+#pragma unroll
+    for (int i = 0; i < GF_IMAGES; ++i) {
+        const int img = img0 + i;
+        if (img >= n) break;
+        f32x4 acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < GF_MAX_Z; ++j) {
+            const int g = j >> 3, h = j & 1, st = (j >> 1) & 3, k = 8 * g + 4 * h + st;  // 0, 4, 1, 5, 2, 6, 3, 7, 8, 12, ...
+            if (k < zd) {
+                const float zk = s_z[i * GF_MAX_Z + k];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = fmaf(zk, w[k][q], acc[q]);
+            }
+        }
+        f32x4 v = acc * sc + sh;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+        store4<E>(out + (size_t)img * ncol + col, v);
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // Last generator layer, fused: ConvTranspose2d(F -> 1, k4, s2, p1) + bias + tanh
 // (reference src/utils/util_dcgan.py:137-138), per-image min/max rescale to [0,1]
@@ -652,6 +704,8 @@ struct gdpso_generator {
     ConvLayer l1, l2;
     const float *w5;
     float b5;
+    const float *w1t = nullptr;  // first layer's weights as [z_dim][k * k * 2F] fp32 (rounded to `dtype`), for gen_first_kernel
+    bool first_direct = false;   // the first layer runs in gen_first_kernel (short latents)
     int num_cus;
     bool last_mfma;            // the last layer runs on the matrix cores (features % 16 == 0, <= 128)
     size_t last_mfma_lds_max;  // dynamic LDS the MFMA kernel may use on this device
@@ -731,6 +785,24 @@ extern "C" int gdpso_generator_create_typed(gdpso_generator **out, int z_dim, in
                 sh[(size_t)p * c1 + co] = sh1[co];
             }
         if ((rc = upload_conv(g->arena, g->l1, packed, sc, sh, dtype))) { delete g; return rc; }
+        const char *e = getenv("GDPSO_GEN_FIRST_DIRECT");
+        g->first_direct = (e ? e[0] != '0' : true) && z_dim <= GF_MAX_Z;
+        if (g->first_direct) {
+            const size_t ncol = (size_t)k * k * c1;
+            std::vector<float> wt((size_t)z_dim * ncol);
+            for (int ci = 0; ci < z_dim; ++ci)
+                for (size_t col = 0; col < ncol; ++col) {
+                    float v = w[col * z_dim + ci];
+                    if (dtype == DT_BF16) {
+                        const uint32_t u = (uint32_t)f32_to_bf16_bits(v) << 16;
+                        std::memcpy(&v, &u, 4);
+                    } else if (dtype == DT_F16) {
+                        v = (float)(_Float16)v;
+                    }
+                    wt[(size_t)ci * ncol + col] = v;
+                }
+            if ((rc = g->arena.upload(wt, &g->w1t))) { delete g; return rc; }
+        }
     }
     {
         std::vector<float> packed, sc, sh;
@@ -786,12 +858,18 @@ extern "C" int gdpso_generator_forward(const gdpso_generator *g, void *stream_, 
     char *ws = (char *)workspace;
     void *zpad = ws + L.zpad, *a1 = ws + L.a1, *a2 = ws + L.a2;
     float *sk = (float *)(ws + L.splitk);
-    const long ne = (long)n * g->kpad;
-    GDPSO_WITH_DTYPE(g->dtype, hipLaunchKernelGGL(latent_prep_kernel<E>, dim3(ceil_div(ne, 256)), dim3(256), 0, stream, z, z_is_f64, n,
-                                                  g->z_dim, g->kpad, (E *)zpad));
     int rc;
     if ((rc = conv_splitk_prepare(stream, sk))) return rc;
-    if ((rc = launch_conv(l1, stream, n, zpad, nullptr, a1, sk))) return rc;
+    if (g->first_direct) {
+        const int ncol = g->k1 * g->k1 * 2 * g->features;
+        GDPSO_WITH_DTYPE(g->dtype, hipLaunchKernelGGL(gen_first_kernel<E>, dim3(ceil_div(ncol / 4, 256), ceil_div(n, GF_IMAGES)), dim3(256), 0,
+                                                      stream, z, z_is_f64, n, g->z_dim, ncol, g->w1t, l1.scale, l1.shift, (E *)a1));
+    } else {
+        const long ne = (long)n * g->kpad;
+        GDPSO_WITH_DTYPE(g->dtype, hipLaunchKernelGGL(latent_prep_kernel<E>, dim3(ceil_div(ne, 256)), dim3(256), 0, stream, z, z_is_f64, n,
+                                                      g->z_dim, g->kpad, (E *)zpad));
+        if ((rc = launch_conv(l1, stream, n, zpad, nullptr, a1, sk))) return rc;
+    }
     if ((rc = launch_conv(l2, stream, n, a1, nullptr, a2, sk))) return rc;
     const int hin = 2 * g->k1;
     const size_t base = ((size_t)g->side * g->side + 32) * sizeof(float);

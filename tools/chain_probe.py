@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Where the chained launch spends its time, step by step (diagnostic build, tools/libgdpso_stamps.so:
-`python tools/stamp_probe.py build` here, then `python tools/chain_probe.py [n]` on the GPU).
+`python tools/stamp_probe.py build` here, then `python tools/chain_probe.py [n [step [dtype]]]` on the GPU; step: the
+one whose tiles also leave the tile code's own stamps, dtype f32 | bf16 | f16).
 
 Per step (over the workgroups of XCD share 0 and over all): when the first / last workgroup entered, how
 long the waits lasted, how long the tiles took, and the hand-off: last signal of step s-1 -> last wait
@@ -26,8 +27,9 @@ def main():
     _lib.LIB_PATH = os.path.join(HERE, "libgdpso_stamps.so")  # the diagnostic build instead of the product library
     lib = _lib.lib()
     dev = torch.device("cuda:0")
-    ass = eng.PackedAssessor(synth.resnet_state("ResNet50", 1, 8, seed=12), dev, img_side=28)
-    gen = eng.PackedGenerator(synth.generator_state(10, 1, 64, seed=11), dev)
+    dtype = sys.argv[3] if len(sys.argv) > 3 else "f32"
+    ass = eng.PackedAssessor(synth.resnet_state("ResNet50", 1, 8, seed=12), dev, img_side=28, dtype=dtype)
+    gen = eng.PackedGenerator(synth.generator_state(10, 1, 64, seed=11), dev, dtype=dtype)
     ev = eng.Evaluator(gen, ass)
     x = torch.rand(n, 28, 28, device=dev)
     for _ in range(3):
