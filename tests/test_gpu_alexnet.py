@@ -91,3 +91,26 @@ def test_alexnet_16bit(synth, dtype, bar):
     ci = sorted(g["iid"].tolist()).index(int(g["label"]))
     fit, _, _ = eng.Evaluator(gen, ass).fitness(torch.from_numpy(g["z"]).cuda(), eng.FitnessSpec(class_index=ci))
     np.testing.assert_allclose(fit.cpu().numpy(), g["fitness"], atol=bar)
+
+
+def test_state_dict_geometry_is_checked_against_fc1(synth):
+    """A plain state dict carries no cnn_args: the padding is read off fc1's width (which the geometry fixes),
+    a padding that contradicts it is refused, and a missing activation is assumed with a warning."""
+    g = load_golden("alexnet")
+    dev = torch.device("cuda:0")
+    eng = imp("engine")
+    sd64 = synth.alexnet_state(8, kernel=3, img_size=64, padding="valid", seed=int(g["seed64"]))
+    assert eng.alexnet_to_linear(64, 3, "valid") == int(g["to_linear64"]) == sd64["fc1.weight"].shape[1]
+    assert eng.alexnet_to_linear(28, 3, "valid") is None and eng.alexnet_to_linear(28, 3, "same") == 256
+    x = torch.from_numpy(g["x64"]).to(dev)
+    want = g["logits64"]
+    cnn_mod = imp("pso.util_cnn")
+    # padding inferred ('valid': 'same' would give another fc1 width), activation given
+    ass = eng.PackedAssessor(sd64, dev, img_side=64, cnn_args={"cnn_activation": "ReLU"})
+    np.testing.assert_allclose(cnn_mod._forward_logits(ass, x).cpu().numpy(), want, rtol=1e-4, atol=TOL)
+    with pytest.raises(ValueError, match="fc1 takes"):
+        eng.PackedAssessor(sd64, dev, img_side=64, cnn_args={"padding": "same", "cnn_activation": "ReLU"})
+    with pytest.raises(ValueError, match="neither padding"):
+        eng.PackedAssessor(sd64, dev, img_side=28, cnn_args={"cnn_activation": "ReLU"})
+    with pytest.warns(UserWarning, match="activation"):
+        eng.PackedAssessor(sd64, dev, img_side=64)

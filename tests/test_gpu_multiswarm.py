@@ -130,3 +130,31 @@ def test_eight_classes_of_32_particles_as_one_batch(eng, synth):
         compared += safe
     assert compared >= 8 * 3  # the comparison is not vacuous
     assert len({float(sw.g_best_val[-1][0]) for sw in together}) > 1  # the classes do differ
+
+
+def test_mixed_history_and_diagnostic_settings(eng, ev):
+    """Swarms of one batch that differ in what they record: each keeps (or drops) its own history and distance
+    diagnostic, the others' are untouched; a second call with other classes of interest rebuilds the class table."""
+    goldens = [load_golden(n) for n in FIXTURES[:2]]
+    sizes, iters = [int(g["n"]) for g in goldens], [int(g["t"]) for g in goldens]
+    batch = eng.HipSwarmBatch(ev, sizes, 10, iters, history=[True, False], diagnostics=[False, True], record_fitness=[True, False])
+    specs, params = [], []
+    for g, hs in zip(goldens, batch.swarms):
+        rand = g["rand"]
+        if rand.shape[0] < int(g["t"]):
+            rand = np.concatenate([rand, np.zeros((int(g["t"]) - rand.shape[0],) + rand.shape[1:])])
+        hs.load(g["pos"][0], g["vel"][0], float(g["w"][0]), rand=rand)
+        specs.append(eng.FitnessSpec(class_index=sorted(g["iid"].tolist()).index(int(g["label"]))))
+        params.append(dict(w_cogn=float(g["w"][1]), w_soci=float(g["w"][2]), schedule_inertia=bool(g["schedule_inertia"]),
+                           early_stopping=bool(g["early_stopping"]), tolerance=float(g["tolerance"]), diagnostics=True))
+    batch.iterate(1, 3, specs, params)
+    r0, r1 = batch.swarms[0].results(), batch.swarms[1].results()
+    assert "hist_pos" in r0 and "fitness" in r0 and "mean_mse" not in r0
+    assert "hist_pos" not in r1 and "fitness" not in r1 and "mean_mse" in r1
+    np.testing.assert_array_equal(r0["hist_pos"][:4], goldens[0]["pos"][:4])
+    np.testing.assert_allclose(r1["mean_mse"][:3], goldens[1]["mean_mse"][:3], rtol=1e-12)
+    table = batch.class_per_image.cpu().numpy().copy()
+    specs[0].class_index = (specs[0].class_index + 1) % 8
+    batch.iterate(4, 1, specs, params)
+    assert (batch.class_per_image.cpu().numpy()[:sizes[0]] == specs[0].class_index).all()
+    assert (batch.class_per_image.cpu().numpy()[sizes[0]:] == table[sizes[0]:]).all()
