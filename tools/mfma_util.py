@@ -31,7 +31,8 @@ def short(name):
 
 
 def generator_rows(rows, key_time, value_of):
-    """value_of(row) for the first and second conv_gemm launch behind each latent_prep launch."""
+    """value_of(row) for the generator's convolution launches: the first and second conv_gemm launch behind a
+    latent_prep launch (G1, G3), or the one launch behind gen_first_kernel (G3; the first layer is that kernel)."""
     rows = sorted(rows, key=key_time)
     out = {"G1": [], "G3": []}
     pending = []
@@ -39,6 +40,8 @@ def generator_rows(rows, key_time, value_of):
         k = short(r["Kernel_Name"])
         if "latent_prep" in k:
             pending = ["G1", "G3"]
+        elif "gen_first_kernel" in k:
+            pending = ["G3"]
         elif pending and "conv_gemm" in k:
             out[pending.pop(0)].append(value_of(r))
     return out

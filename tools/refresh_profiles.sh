@@ -15,13 +15,13 @@ export TMPDIR=/tmp
 
 timeout -k 10 300 python3 bench.py $ARGS > $OUT/bench.json 2> $OUT/bench.err
 echo "bench done"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --no-cpu-baseline $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --no-cpu-baseline --no-reference-shape $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
 echo "kernel trace done"
-timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline $ARGS > $OUT/pmc_fetch.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-reference-shape $ARGS > $OUT/pmc_fetch.log 2>&1
 echo "fetch pass done"
-timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline $ARGS > $OUT/pmc_write.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-reference-shape $ARGS > $OUT/pmc_write.log 2>&1
 echo "write pass done"
-timeout -s KILL 120 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $OUT/pmc_mfma -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline $ARGS > $OUT/pmc_mfma.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $OUT/pmc_mfma -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-reference-shape $ARGS > $OUT/pmc_mfma.log 2>&1
 echo "mfma pass done"
 
 STATS=$(find $OUT/prof -name '*kernel_stats.csv' | head -1)

@@ -14,7 +14,9 @@ def main():
     full = "--full" in sys.argv
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    idx = [i for i, r in enumerate(rows) if "latent_prep" in r["Kernel_Name"]]
+    # an iteration begins with the generator's first kernel (latents in): gen_first_kernel, or latent_prep ahead
+    # of a first layer on the matrix cores
+    idx = [i for i, r in enumerate(rows) if "latent_prep" in r["Kernel_Name"] or "gen_first_kernel" in r["Kernel_Name"]]
     if len(idx) < 2:
         raise SystemExit("fewer than two iterations in the trace")
     # the stretches between two generator passes that hold a PSO step (the benchmark ends with passes of
