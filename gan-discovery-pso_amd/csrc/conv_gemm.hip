@@ -180,6 +180,36 @@ __device__ __forceinline__ unsigned chain_peek(const ChainWait &w, int tid) {
     return tid < w.count ? __hip_atomic_load(w.flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
 }
 
+// How the tile code reads a layer's arguments: `a->field`, and a.in() / a.res() / a.out() for the three buffers.
+// ArgsDirect: the kernel's own parameter (loads from the kernel-argument segment, placed where the values are
+// first used or demanded).  ArgsChain: a record of a chain's step list in constant memory, read the same way,
+// field by field where needed; copied whole into registers at the top of a step, its ~56 words stayed live
+// across the tile and the compiler kept moving them between SGPRs and VGPR lanes (500 lane moves in the
+// chained kernel, none in the others).  in / res / out hold byte offsets into the chain's workspace there;
+// `gaps` = gap_in[2], gap_res[2], gap_out[2] of the step, `which` the layer of the step.
+struct ArgsDirect {
+    const ConvKArgs &r;
+    __device__ __forceinline__ const ConvKArgs *operator->() const { return &r; }
+    __device__ __forceinline__ const void *in() const { return r.in; }
+    __device__ __forceinline__ const void *res() const { return r.res; }
+    __device__ __forceinline__ void *out() const { return r.out; }
+};
+struct ArgsChain {
+    typedef const __attribute__((address_space(4))) ConvKArgs *args_ptr;
+    typedef const __attribute__((address_space(4))) unsigned *gaps_ptr;
+    args_ptr p;
+    gaps_ptr gaps;
+    char *ws;
+    int share, which;
+    __device__ __forceinline__ args_ptr operator->() const { return p; }
+    __device__ __forceinline__ const void *in() const { return ws + (size_t)p->in + (size_t)share * gaps[which]; }
+    __device__ __forceinline__ const void *res() const {
+        const void *const r = p->res;
+        return r == (const void *)~(uintptr_t)0 ? nullptr : (const void *)(ws + (size_t)r + (size_t)share * gaps[2 + which]);
+    }
+    __device__ __forceinline__ void *out() const { return ws + (size_t)p->out + (size_t)share * gaps[4 + which]; }
+};
+
 // What a workgroup needs to know about its phase (all wave-uniform).
 struct PhaseInfo {
     int M, hm, wm;      // rows of this phase = n_images * hm * wm
@@ -236,16 +266,16 @@ struct StorePlan {
     f32x4 rres[PREFETCH_RES ? PASSES : 1];
 };
 
-template <typename E, int BM, int BN, bool CHAIN = false>
-__device__ __forceinline__ void conv_store_plan(const ConvKArgs &a, int tid, int m0, int n0, const PhaseInfo &P,
+template <typename E, int BM, int BN, bool CHAIN = false, typename ARGS>
+__device__ __forceinline__ void conv_store_plan(const ARGS &a, int tid, int m0, int n0, const PhaseInfo &P,
                                                 StorePlan<BM, BN> &sp) {
     using Plan = StorePlan<BM, BN>;
     const int hw = P.hm * P.wm;
     const int c4 = tid % Plan::C4, r0 = tid / Plan::C4;
     const int col = n0 + c4 * 4;
-    sp.sc = *(global_f32x4_ptr)(a.scale + col);
-    sp.sh = *(global_f32x4_ptr)(a.shift + col);
-    const bool remap = a.out_mul != 1 || P.hm != a.hout || P.wm != a.wout;
+    sp.sc = *(global_f32x4_ptr)(a->scale + col);
+    sp.sh = *(global_f32x4_ptr)(a->shift + col);
+    const bool remap = a->out_mul != 1 || P.hm != a->hout || P.wm != a->wout;
     // 32-bit offsets are enough, the host refuses outputs of 2 GiB and more
 #pragma unroll
     for (int pass = 0; pass < Plan::PASSES; ++pass) {
@@ -253,15 +283,15 @@ __device__ __forceinline__ void conv_store_plan(const ConvKArgs &a, int tid, int
         // straight-line (a branch per pass made the compiler re-fetch its arguments behind every one)
         const int n = fast_div(m, P.hw_mul, P.hw_shift), rr = m - n * hw;
         const int my = fast_div(rr, P.wm_mul, P.wm_shift), mx = rr - my * P.wm;
-        const int pix = remap ? (n * a.hout + my * a.out_mul + P.off_y) * a.wout + mx * a.out_mul + P.off_x : m;
-        sp.off[pass] = m < P.M ? pix * a.cout + col : -1;
+        const int pix = remap ? (n * a->hout + my * a->out_mul + P.off_y) * a->wout + mx * a->out_mul + P.off_x : m;
+        sp.off[pass] = m < P.M ? pix * a->cout + col : -1;
     }
     if constexpr (Plan::PREFETCH_RES) {
         // rows past M read the first row's residual (any valid address; the value is not used)
-        const bool want = a.splits == 1 && a.res != nullptr;
+        const bool want = a->splits == 1 && a.res() != nullptr;
         if constexpr (CHAIN) {
             // written earlier in this launch by a workgroup of the same XCD: read past the L1 (sc1)
-            const __amdgpu_buffer_rsrc_t rsrc_res = __builtin_amdgcn_make_buffer_rsrc((void *)a.res, 0, (int)(a.slab * sizeof(E)), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsrc_res = __builtin_amdgcn_make_buffer_rsrc((void *)a.res(), 0, (int)(a->slab * sizeof(E)), 0x00020000);
 #pragma unroll
             for (int pass = 0; pass < Plan::PASSES; ++pass) {
                 sp.rres[pass] = 0.f;
@@ -281,7 +311,7 @@ __device__ __forceinline__ void conv_store_plan(const ConvKArgs &a, int tid, int
 #pragma unroll
             for (int pass = 0; pass < Plan::PASSES; ++pass) {
                 sp.rres[pass] = 0.f;
-                if (want) sp.rres[pass] = load4<E>((const E *)a.res + (sp.off[pass] < 0 ? col : sp.off[pass]));
+                if (want) sp.rres[pass] = load4<E>((const E *)a.res() + (sp.off[pass] < 0 ? col : sp.off[pass]));
             }
         }
     }
@@ -294,11 +324,11 @@ __device__ __forceinline__ void conv_store_plan(const ConvKArgs &a, int tid, int
 // row segments, and the residual is read the same way.
 // KP > 1: the tile arrives as KP partial tiles (regions of BM x (BN + 4) floats, one per K part
 // of the workgroup), which are added in the order 0, 1, ... as they are read.
-template <typename E, int BM, int BN, int KP = 1>
-__device__ __forceinline__ void conv_store_tile(const ConvKArgs &a, float *lds, int lds_floats, int tid, int sp, int tile,
+template <typename E, int BM, int BN, int KP = 1, typename ARGS>
+__device__ __forceinline__ void conv_store_tile(const ARGS &a, float *lds, int lds_floats, int tid, int sp, int tile,
                                                 const StorePlan<BM, BN> &plan) {
-    E *const out = (E *)a.out;
-    const E *const res = (const E *)a.res;
+    E *const out = (E *)a.out();
+    const E *const res = (const E *)a.res();
     using Plan = StorePlan<BM, BN>;
     constexpr int LDC = BN + 4;
     float *sC = lds;
@@ -310,11 +340,11 @@ __device__ __forceinline__ void conv_store_tile(const ConvKArgs &a, float *lds, 
     };
     constexpr int RPP = Plan::RPP, PASSES = Plan::PASSES;
     const int r0 = tid / Plan::C4;
-    const bool direct = a.splits == 1;
+    const bool direct = a->splits == 1;
     const f32x4 sc = plan.sc, sh = plan.sh;
     const int(&off)[PASSES] = plan.off;
     if (direct) {
-        const float slope = act_slope(a.act);
+        const float slope = act_slope(a->act);
 #pragma unroll
         for (int pass = 0; pass < PASSES; ++pass) {
             if constexpr (Plan::PREFETCH_RES) {
@@ -343,15 +373,15 @@ __device__ __forceinline__ void conv_store_tile(const ConvKArgs &a, float *lds, 
     // slab stores, which need no L2 write-back; every wave drains its stores; workgroup
     // barrier; one lane adds to the counter.  The last arriver takes one agent-scope acquire
     // (drops this CU's stale L1 lines) before anyone loads.
-    float *slab = a.part + (size_t)sp * a.slab;
-    if (a.counters == nullptr) {  // reduction by the separate kernel
+    float *slab = a->part + (size_t)sp * a->slab;
+    if (a->counters == nullptr) {  // reduction by the separate kernel
 #pragma unroll
         for (int pass = 0; pass < PASSES; ++pass)
             if (off[pass] >= 0) *(f32x4 *)(slab + off[pass]) = tile_quad(pass * RPP + r0);
         return;
     }
     {
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(slab, 0, (int)(a.slab * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(slab, 0, (int)(a->slab * 4), 0x00020000);
 #pragma unroll
         for (int pass = 0; pass < PASSES; ++pass)
             if (off[pass] >= 0)
@@ -363,9 +393,9 @@ __device__ __forceinline__ void conv_store_tile(const ConvKArgs &a, float *lds, 
     __syncthreads();
     int *s_last = (int *)&lds[lds_floats - 4];  // past the output tile
     if (tid == 0) {
-        int *cnt = a.counters + tile;
+        int *cnt = a->counters + tile;
         const int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = ticket == a.splits - 1;
+        const int last = ticket == a->splits - 1;
         if (last) {
             __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -378,13 +408,13 @@ __device__ __forceinline__ void conv_store_tile(const ConvKArgs &a, float *lds, 
 #pragma unroll
     for (int pass = 0; pass < PASSES; ++pass) {
         if (off[pass] < 0) continue;
-        f32x4 v = *(const f32x4 *)(a.part + off[pass]);
+        f32x4 v = *(const f32x4 *)(a->part + off[pass]);
 #pragma unroll 4
-        for (int k = 1; k < a.splits; ++k) v += *(const f32x4 *)(a.part + (size_t)k * a.slab + off[pass]);
+        for (int k = 1; k < a->splits; ++k) v += *(const f32x4 *)(a->part + (size_t)k * a->slab + off[pass]);
         v = v * sc + sh;
         if (res) v += load4<E>(res + off[pass]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = apply_act(v[q], a.act);
+        for (int q = 0; q < 4; ++q) v[q] = apply_act(v[q], a->act);
         store4<E>(out + off[pass], v);
     }
 }
@@ -413,8 +443,8 @@ __device__ __forceinline__ f32x16 mfma16(const f32x4 &a, const f32x4 &b, const f
 // activations (A operand, residual) were written earlier in the same launch by workgroups on the same
 // XCD and are read with sc1 loads, which miss the CU's L1 and hit the XCD's L2; the tile's first
 // activation load waits for `wait` (weights, tables and arguments are fetched ahead of the wait).
-template <typename E, int BM, int BN, int BKT, int KW, bool FUSE = false, bool CHAIN = false>
-__device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int slot, float *lds, const FuseArgs *fuse = nullptr,
+template <typename E, int BM, int BN, int BKT, int KW, bool FUSE = false, bool CHAIN = false, typename ARGS>
+__device__ __forceinline__ void conv_tile(const ARGS &a, const int xcd, int slot, float *lds, const FuseArgs *fuse = nullptr,
                                           const ChainWait wait = ChainWait{}) {
     constexpr int VEC = vec_of<E>();  // elements per 16-byte vector
     constexpr bool F32 = is_f32<E>();
@@ -440,7 +470,7 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
     static_assert(LDS_FLOATS >= BM * (BN + 4) + 4, "the output tile is staged in the operand buffers");
     E *sA = (E *)lds;
     E *sB = sA + 2 * BM * LDA;
-    const E *const in = (const E *)a.in;
+    const E *const in = (const E *)a.in();
 
 #ifdef GDPSO_STAMPS
     // a chain stamps the tiles of one chosen step only; `g_stamps` below is then this pointer, already offset
@@ -462,11 +492,11 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
     // Everything the prologue reads from the kernel arguments is demanded here, in one statement
     // (30 operands at most): fetched where first used, the arguments cost the prologue a chain of
     // scalar-load round trips of ~0.25 us each ahead of the first operand load.
-#define GDPSO_W(I) "s"(a.phase_word[I])
+#define GDPSO_W(I) "s"(a->phase_word[I])
     static_assert(MAX_PHASES == 16, "the operand list names 16 phases");
-    asm volatile("" ::"s"(a.in), "s"(a.wt), "s"(a.wtq), "s"(a.table), "s"(a.n_images), "s"(a.hin), "s"(a.win), "s"(a.cin),
-                 "s"(a.in_stride), "s"(a.splits), "s"(a.tiles_n), "s"(a.per_xcd), "s"(a.snake), "s"(a.tiles_n_mul),
-                 "s"(a.tiles_n_shift), GDPSO_W(0), GDPSO_W(1), GDPSO_W(2), GDPSO_W(3), GDPSO_W(4), GDPSO_W(5), GDPSO_W(6),
+    asm volatile("" ::"s"(a.in()), "s"(a->wt), "s"(a->wtq), "s"(a->table), "s"(a->n_images), "s"(a->hin), "s"(a->win), "s"(a->cin),
+                 "s"(a->in_stride), "s"(a->splits), "s"(a->tiles_n), "s"(a->per_xcd), "s"(a->snake), "s"(a->tiles_n_mul),
+                 "s"(a->tiles_n_shift), GDPSO_W(0), GDPSO_W(1), GDPSO_W(2), GDPSO_W(3), GDPSO_W(4), GDPSO_W(5), GDPSO_W(6),
                  GDPSO_W(7), GDPSO_W(8), GDPSO_W(9), GDPSO_W(10), GDPSO_W(11), GDPSO_W(12), GDPSO_W(13), GDPSO_W(14),
                  GDPSO_W(15));
 #undef GDPSO_W
@@ -474,28 +504,28 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
     // An XCD deals its workgroups round-robin to its CUs: with two per CU and phases in order of
     // decreasing cost, CU i would get the i-th heaviest and the (i + CUs)-th heaviest.  Dealing the
     // second round from the light end pairs heavy with light.
-    if (a.snake && slot >= a.snake) slot = a.per_xcd - 1 - (slot - a.snake);
+    if (a->snake && slot >= a->snake) slot = a->per_xcd - 1 - (slot - a->snake);
     // The phase of this slot: the first whose running end exceeds it.  The ends increase, so
     // `past` holds for p < ph exactly and the xor chain telescopes to phase_word[ph] (a chain of
     // selects over the array would be turned into a load indexed by ph, from a scratch copy).
     int ph = 0, base = 0;
-    unsigned sel = a.phase_word[0];
-    if (a.phase_word[1] != 0xffffffu) {  // single-phase layers (every 1x1 convolution) have nothing to search
+    unsigned sel = a->phase_word[0];
+    if (a->phase_word[1] != 0xffffffu) {  // single-phase layers (every 1x1 convolution) have nothing to search
 #pragma unroll
         for (int p = 0; p < MAX_PHASES - 1; ++p) {
-            const int end_p = (int)(a.phase_word[p] & 0xffffffu);
+            const int end_p = (int)(a->phase_word[p] & 0xffffffu);
             // integer forms throughout, so that the chain stays on the scalar unit
             const int past = (int)((unsigned)(end_p - 1 - slot) >> 31);  // slot >= end_p
             ph += past;
             base = max(base, end_p & -past);
-            sel ^= (a.phase_word[p + 1] ^ a.phase_word[p]) & (unsigned)-past;
+            sel ^= (a->phase_word[p + 1] ^ a->phase_word[p]) & (unsigned)-past;
         }
     }
     const int per_xcd = (int)(sel & 0xffffffu) - base;
     // a chain counts a phase's tiles per share (its slot is the tile's index inside the share's rows of the phase)
     const int idx = CHAIN ? slot - base : xcd * per_xcd + (slot - base);
     if (!CHAIN && idx >= 8 * per_xcd - (int)(sel >> 24)) return;
-    const int tml = fast_div(idx, a.tiles_n_mul, a.tiles_n_shift), tn = idx - tml * a.tiles_n;
+    const int tml = fast_div(idx, a->tiles_n_mul, a->tiles_n_shift), tn = idx - tml * a->tiles_n;
     int m0 = tml * BM;
     const int n0 = tn * BN;
     const int sp = CHAIN ? 0 : blockIdx.z;
@@ -503,7 +533,7 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
     // else the kernel does (behind an asm statement or a store the compiler assumes that global
     // memory may have changed, and falls back to vector loads).
     typedef const __attribute__((address_space(4))) int *const_int_ptr;
-    const const_int_ptr tab = (const_int_ptr)(uintptr_t)(a.table + ph * PHASE_TABLE_INTS);
+    const const_int_ptr tab = (const_int_ptr)(uintptr_t)(a->table + ph * PHASE_TABLE_INTS);
     int hdr[PHASE_HDR + 1];
 #pragma unroll
     for (int i = 0; i <= PHASE_HDR; ++i) hdr[i] = tab[i];  // (the first tap comes with the header: one scalar-load round trip fewer)
@@ -514,7 +544,7 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
     P.off_x = hdr[2];
     P.hm = hdr[4];
     P.wm = hdr[5];
-    P.M = a.n_images * P.hm * P.wm;
+    P.M = a->n_images * P.hm * P.wm;
     P.hw_mul = (unsigned)hdr[9];
     P.wm_mul = (unsigned)hdr[10];
     P.hw_shift = (unsigned)hdr[11] & 0xff;
@@ -523,7 +553,7 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
     if constexpr (CHAIN) {
         // the share's rows of this phase: tiles start at its first row, the last one may be partly (or, in
         // the last shares of a batch that does not divide by the number of shares, wholly) past its end
-        const int share_rows = a.share_images * P.hm * P.wm;
+        const int share_rows = a->share_images * P.hm * P.wm;
         m0 += xcd * share_rows;
         P.M = min(P.M, (xcd + 1) * share_rows);
         if (m0 >= P.M) {
@@ -538,10 +568,10 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
     asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(wstride), "s"(ntaps) : "memory");  // the phase header has arrived
     GDPSO_STAMP(8)
 #endif
-    const E *wt = (const E *)a.wt + hdr[3];
-    const int ktot = ntaps * a.cin;
+    const E *wt = (const E *)a->wt + hdr[3];
+    const int ktot = ntaps * a->cin;
     // this phase's K range per split (the divide only where K is split at all)
-    const int ksplit = a.splits == 1 ? ktot : ((ktot / BKT + a.splits - 1) / a.splits) * BKT;
+    const int ksplit = a->splits == 1 ? ktot : ((ktot / BKT + a->splits - 1) / a->splits) * BKT;
     const int kbeg = sp * ksplit;
     const int kend = min(ktot, kbeg + ksplit);
 
@@ -557,9 +587,9 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
         const int mm = a_ok[p] ? m : 0;
         const int n = fast_div(mm, P.hw_mul, P.hw_shift), r = mm - n * hw;
         const int my = fast_div(r, P.wm_mul, P.wm_shift), mx = r - my * P.wm;
-        a_iy0[p] = my * a.in_stride + in_y0;
-        a_ix0[p] = mx * a.in_stride + in_x0;
-        a_img[p] = n * a.hin * a.win;
+        a_iy0[p] = my * a->in_stride + in_y0;
+        a_ix0[p] = mx * a->in_stride + in_x0;
+        a_img[p] = n * a->hin * a->win;
     }
     // Gather pointers advance by one K-tile (32 channels) per load and are recomputed only
     // when the K range crosses into the next tap.  Rows whose tap falls in the padding (only
@@ -568,13 +598,13 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
     // dy | dx << 8 | (position of the tap in the weight rows) << 16.
     const E *aptr[PA], *bptr[PB];
     const E *brow[PB];
-    // CHAIN: the A operand goes through buffer loads (byte offsets from a.in; the sc1 bit makes them miss
+    // CHAIN: the A operand goes through buffer loads (byte offsets from a.in(); the sc1 bit makes them miss
     // the L1); rows in the padding point past the end of the buffer, where a buffer load returns zeros
     unsigned aoff[PA];
     constexpr unsigned A_OUTSIDE = 0xC0000000u;  // stays out of range however far the K loop advances it
     __amdgpu_buffer_rsrc_t rsrc_in;
     if constexpr (CHAIN)
-        rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, a.n_images * a.hin * a.win * a.cin * (int)sizeof(E), 0x00020000);
+        rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, a->n_images * a->hin * a->win * a->cin * (int)sizeof(E), 0x00020000);
 #pragma unroll
     for (int p = 0; p < PB; ++p) brow[p] = wt + ((n0 + lrow + RP * p) * wstride + lcol);  // 32-bit offsets: see conv_args
     // BD: this lane's chunk 0 of the K-tile at weight-row position 0: column block (n0 + wc * BN / 2) / 32, column
@@ -582,20 +612,20 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
     // fragments of a K-tile (chunks 2 g + half) 64 * VEC elements apart
     const E *bq0 = nullptr, *bqp = nullptr;
     if constexpr (BD)
-        bq0 = (const E *)a.wtq + hdr[3] + ((size_t)((n0 + wc * (BN / 2)) >> 5) * (wstride / VEC) * 32 + l31 + (kh * 8 + half) * 32) * VEC;
-    int tap = a.splits == 1 ? 0 : kbeg / a.cin, ci0 = kbeg - tap * a.cin;
+        bq0 = (const E *)a->wtq + hdr[3] + ((size_t)((n0 + wc * (BN / 2)) >> 5) * (wstride / VEC) * 32 + l31 + (kh * 8 + half) * 32) * VEC;
+    int tap = a->splits == 1 ? 0 : kbeg / a->cin, ci0 = kbeg - tap * a->cin;
 #define GDPSO_SET_TAP(CI, PACKED)                                                                               \
     {                                                                                                           \
         const int packed_ = (PACKED);                                                                           \
         const int dy_ = (int)(signed char)(packed_ & 0xff), dx_ = (int)(signed char)((packed_ >> 8) & 0xff);    \
-        const int wk_ = (packed_ >> 16) * a.cin + (CI);                                                         \
+        const int wk_ = (packed_ >> 16) * a->cin + (CI);                                                         \
         _Pragma("unroll") for (int p = 0; p < PA; ++p) {                                                        \
             const int iy = a_iy0[p] + dy_, ix = a_ix0[p] + dx_;                                                 \
-            const bool ok = a_ok[p] && (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;        \
+            const bool ok = a_ok[p] && (unsigned)iy < (unsigned)a->hin && (unsigned)ix < (unsigned)a->win;        \
             if constexpr (CHAIN)                                                                                \
-                aoff[p] = ok ? (unsigned)((a_img[p] + iy * a.win + ix) * a.cin + (CI) + lcol) * (unsigned)sizeof(E) : A_OUTSIDE; \
+                aoff[p] = ok ? (unsigned)((a_img[p] + iy * a->win + ix) * a->cin + (CI) + lcol) * (unsigned)sizeof(E) : A_OUTSIDE; \
             else                                                                                                \
-                aptr[p] = ok ? in + ((a_img[p] + iy * a.win + ix) * a.cin + (CI) + lcol)                        \
+                aptr[p] = ok ? in + ((a_img[p] + iy * a->win + ix) * a->cin + (CI) + lcol)                        \
                              : (const E *)g_zero_page + (CI) + lcol;                                            \
         }                                                                                                       \
         if constexpr (BD)                                                                                       \
@@ -652,7 +682,7 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
         else                                                                                                    \
             _Pragma("unroll") for (int p = 0; p < PB; ++p) bptr[p] += BKT;                                      \
         ci0 += BKT;                                                                                             \
-        if (ci0 == a.cin) {                                                                                     \
+        if (ci0 == a->cin) {                                                                                     \
             ci0 = 0;                                                                                            \
             if (++tap < ntaps) GDPSO_SET_TAP(0, tab[PHASE_HDR + tap])                                           \
         }                                                                                                       \
@@ -720,8 +750,8 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
     // What the epilogue reads from the kernel arguments is demanded here, so that it arrives during
     // the K loop: fetched where first used, each argument costs the epilogue a scalar-load round trip.
     if constexpr (!FUSE)
-        asm volatile("" ::"s"(a.scale), "s"(a.shift), "s"(a.res), "s"(a.out), "s"(a.part), "s"(a.counters), "s"(a.cout),
-                     "s"(a.hout), "s"(a.wout), "s"(a.out_mul), "s"(a.act), "s"(a.slab));
+        asm volatile("" ::"s"(a->scale), "s"(a->shift), "s"(a.res()), "s"(a.out()), "s"(a->part), "s"(a->counters), "s"(a->cout),
+                     "s"(a->hout), "s"(a->wout), "s"(a->out_mul), "s"(a->act), "s"(a->slab));
     __syncthreads();
     GDPSO_STAMP(1)
     // One K-tile.  Within it the 32 k's of a wave are consumed in a permuted order: MFMA step s of
@@ -909,21 +939,21 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
         float *sA2 = lds, *sB2 = lds + 64 * LD2, *sC2 = lds + 2 * 64 * LD2;
         {
             const int col = wc * 32 + l31;
-            const float sc1 = a.scale[n0 + col], sh1 = a.shift[n0 + col];
+            const float sc1 = a->scale[n0 + col], sh1 = a->shift[n0 + col];
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                sA2[(wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LD2 + col] = apply_act(acc[0][0][r] * sc1 + sh1, a.act);
+                sA2[(wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LD2 + col] = apply_act(acc[0][0][r] * sc1 + sh1, a->act);
         }
         const int c4 = tid & 15, r0 = tid >> 4;  // 16 threads x 16 B per 64-float row, 16 rows per pass
         const int hw2 = P.hm * P.wm;
-        const bool remap = a.out_mul != 1 || P.hm != a.hout || P.wm != a.wout;
+        const bool remap = a->out_mul != 1 || P.hm != a->hout || P.wm != a->wout;
         int off[4];
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
             const int m = m0 + pass * 16 + r0;
             const int n = fast_div(m, P.hw_mul, P.hw_shift), rr = m - n * hw2;
             const int my = fast_div(rr, P.wm_mul, P.wm_shift), mx = rr - my * P.wm;
-            const int pix = remap ? (n * a.hout + my * a.out_mul + P.off_y) * a.wout + mx * a.out_mul + P.off_x : m;
+            const int pix = remap ? (n * a->hout + my * a->out_mul + P.off_y) * a->wout + mx * a->out_mul + P.off_x : m;
             off[pass] = m < P.M ? pix * f.cout + c4 * 4 : -1;
         }
         const int nblocks = f.cout / 64;
@@ -1010,14 +1040,14 @@ __device__ __forceinline__ void conv_tile(const ConvKArgs &a, const int xcd, int
 template <typename E, int BM, int BN, int BKB, int KW>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * (BKB / 4 + 4)];
-    conv_tile<E, BM, BN, BKB / (int)sizeof(E), KW>(a, blockIdx.x & 7, blockIdx.x >> 3, lds);
+    conv_tile<E, BM, BN, BKB / (int)sizeof(E), KW>(ArgsDirect{a}, blockIdx.x & 7, blockIdx.x >> 3, lds);
 }
 
 // A convolution with 64 output channels followed by a 1x1 convolution, one launch: conv2 + conv3
 // of the first-stage bottleneck blocks.  The intermediate never leaves the workgroup.
 __global__ __launch_bounds__(256, 2) void conv_gemm_fused_kernel(const ConvKArgs a, const FuseArgs f) {
     __shared__ __attribute__((aligned(16))) float lds[3 * 64 * 68];
-    conv_tile<float, 64, 64, 32, 1, true>(a, blockIdx.x & 7, blockIdx.x >> 3, lds, &f);
+    conv_tile<float, 64, 64, 32, 1, true>(ArgsDirect{a}, blockIdx.x & 7, blockIdx.x >> 3, lds, &f);
 }
 
 // Two independent layers in one grid (same tile shape, no split-K): the first tiles_a workgroups
@@ -1029,9 +1059,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_pair_kernel(const ConvKArgs 
     __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * (BKB / 4 + 4)];
     // two copies of the tile code, each reading its own kernel arguments straight from SGPRs
     if ((int)blockIdx.x < tiles_a)
-        conv_tile<E, BM, BN, BKB / (int)sizeof(E), KW>(a, blockIdx.x & 7, blockIdx.x >> 3, lds);
+        conv_tile<E, BM, BN, BKB / (int)sizeof(E), KW>(ArgsDirect{a}, blockIdx.x & 7, blockIdx.x >> 3, lds);
     else
-        conv_tile<E, BM, BN, BKB / (int)sizeof(E), KW>(b, (blockIdx.x - tiles_a) & 7, (blockIdx.x - tiles_a) >> 3, lds);
+        conv_tile<E, BM, BN, BKB / (int)sizeof(E), KW>(ArgsDirect{b}, (blockIdx.x - tiles_a) & 7, (blockIdx.x - tiles_a) >> 3, lds);
 }
 
 // ----------------------------------------------------------------------------- layer chains
@@ -1075,27 +1105,6 @@ struct ChainCtl {  // zeroed ahead of every launch
     unsigned cu_first[8][256];                      // 1 + the ticket of the CU's first workgroup
     unsigned flags[CHAIN_MAX_SHARES][CHAIN_MAX_MEMBERS];  // per share and member: steps finished (1 + the last step's index)
 };
-
-__device__ __forceinline__ ConvKArgs chain_load_args(const ChainStep *steps, int s, int which, char *ws, int share) {
-    // copied word by word through the constant address space: scalar loads into SGPRs
-    typedef const __attribute__((address_space(4))) unsigned *const_u32_ptr;
-    static_assert(sizeof(ConvKArgs) % 4 == 0, "ConvKArgs is copied in 32-bit words");
-    constexpr int WORDS = (int)sizeof(ConvKArgs) / 4;
-    union {
-        ConvKArgs a;
-        unsigned w[WORDS];
-    } u;
-    const const_u32_ptr src = (const_u32_ptr)(uintptr_t)&steps[s].a[which];
-#pragma unroll
-    for (int i = 0; i < WORDS; ++i) u.w[i] = src[i];
-    ConvKArgs a = u.a;
-    typedef const __attribute__((address_space(4))) unsigned *const_gap_ptr;
-    const const_gap_ptr gaps = (const_gap_ptr)(uintptr_t)steps[s].gap_in;  // gap_in[2], gap_res[2], gap_out[2]
-    a.in = ws + (size_t)a.in + (size_t)share * gaps[which];
-    a.out = ws + (size_t)a.out + (size_t)share * gaps[4 + which];
-    a.res = a.res == (const void *)~(uintptr_t)0 ? nullptr : (const void *)(ws + (size_t)a.res + (size_t)share * gaps[2 + which]);
-    return a;
-}
 
 #ifdef GDPSO_STAMPS
 // Diagnostic build only (tools/chain_probe.py): per workgroup and step, s_memrealtime (100 MHz) when
@@ -1222,7 +1231,7 @@ __global__ __launch_bounds__(256, 2) void conv_chain_kernel(const ChainStep *ste
 #endif
                 }
                 if (!first) __syncthreads();  // the previous tile's store pass has left the LDS
-                const ConvKArgs a = chain_load_args(steps, s, which, ws, share);
+                const ArgsChain a{(ArgsChain::args_ptr)(uintptr_t)&steps[s].a[which], (ArgsChain::gaps_ptr)(uintptr_t)steps[s].gap_in, ws, share, which};
                 if (shape == 64)
                     conv_tile<E, 64, 64, 128 / (int)sizeof(E), 1, false, true>(a, share, slot, lds, nullptr, w);
                 else if (shape == 32)
