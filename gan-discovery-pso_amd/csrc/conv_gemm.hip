@@ -851,6 +851,23 @@ __device__ __forceinline__ void conv_tile(const ARGS &a, const int xcd, int slot
             GDPSO_SGB(0x008, 1) GDPSO_SGB(0x200, (NW + 1) / 4)                                                  \
             GDPSO_SGB(0x008, 1) GDPSO_SGB(0x200, NW / 4)                                                        \
             GDPSO_SGB(0x008, 3)                                                                                 \
+        } else if constexpr (WM * WN == 2) {                                                                    \
+            /* 1 x 2 blocks (64x128): 32 MFMAs, 8 a group; the next group's three fragment reads behind the   */ \
+            /* group's first three, then the K-tile's six loads (groups 0, 1) or LDS stores (groups 2, 3)     */ \
+            static_assert(WM == 1 && WN == 2 && PA + PB == 6, "pinned for the 64x128 tile");                    \
+            constexpr int NV = (LOAD) ? 1 : 0, NW = (MORE) ? 1 : 0;                                             \
+            GDPSO_SGB(0x100, 3)                                                                                 \
+            GDPSO_SGB(0x008, 1) GDPSO_SGB(0x100, 1) GDPSO_SGB(0x008, 1) GDPSO_SGB(0x100, 1) GDPSO_SGB(0x008, 1) GDPSO_SGB(0x100, 1) \
+            GDPSO_SGB(0x008, 1) GDPSO_SGB(0x020, NV) GDPSO_SGB(0x008, 1) GDPSO_SGB(0x020, NV) GDPSO_SGB(0x008, 1) GDPSO_SGB(0x020, NV) \
+            GDPSO_SGB(0x008, 2)                                                                                 \
+            GDPSO_SGB(0x008, 1) GDPSO_SGB(0x100, 1) GDPSO_SGB(0x008, 1) GDPSO_SGB(0x100, 1) GDPSO_SGB(0x008, 1) GDPSO_SGB(0x100, 1) \
+            GDPSO_SGB(0x008, 1) GDPSO_SGB(0x020, NV) GDPSO_SGB(0x008, 1) GDPSO_SGB(0x020, NV) GDPSO_SGB(0x008, 1) GDPSO_SGB(0x020, NV) \
+            GDPSO_SGB(0x008, 2)                                                                                 \
+            GDPSO_SGB(0x008, 1) GDPSO_SGB(0x100, 1) GDPSO_SGB(0x008, 1) GDPSO_SGB(0x100, 1) GDPSO_SGB(0x008, 1) GDPSO_SGB(0x100, 1) \
+            GDPSO_SGB(0x008, 1) GDPSO_SGB(0x200, NW) GDPSO_SGB(0x008, 1) GDPSO_SGB(0x200, NW) GDPSO_SGB(0x008, 1) GDPSO_SGB(0x200, NW) \
+            GDPSO_SGB(0x008, 2)                                                                                 \
+            GDPSO_SGB(0x008, 1) GDPSO_SGB(0x200, NW) GDPSO_SGB(0x008, 1) GDPSO_SGB(0x200, NW) GDPSO_SGB(0x008, 1) GDPSO_SGB(0x200, NW) \
+            GDPSO_SGB(0x008, 5)                                                                                 \
         } else {                                                                                                \
             /* 2 x 2 blocks: 64 MFMAs in pairs; per group of 16: the next group's four fragment reads    */    \
             /* behind the first four pairs, then a load (groups 0, 1) or two LDS stores (groups 2, 3)     */    \
@@ -1091,10 +1108,16 @@ constexpr int CHAIN_MAX_MEMBERS = 1024;  // workgroups of one launch (all of the
 // slices, one per share, whatever the layer: share s keeps its rows of every intermediate at
 // slice s (`gap` = slice size - the layer's bytes per share, added to the base once per share), the
 // chain's input is only read, and its final output has a buffer of its own.
+// Tile shape code of a chain step only: 64 rows x 128 columns (2 x 2 waves, two MFMA blocks side by side per
+// wave).  Every output is the same sum in the same order as with the 64x64 tile (each wave walks the whole K of
+// its rows), so a layer the planner gave 64x64 tiles may run 64x128 as a step of a chain without its bits
+// changing; a chain takes it for steps that would otherwise hand a workgroup several 64x64 tiles (each tile
+// pays its prologue, operand fetch and epilogue again, ~3 us that no K loop of the step hides).
+constexpr int TILE_64x128 = 129;
 struct ChainStep {
     ConvKArgs a[2];  // one layer, or two that read the same input; in / res / out hold byte offsets into the workspace
     int tiles[2];    // tiles per share of each (0: absent)
-    int shape[2];    // tile shape code of each (64, 32, TILE_32x32)
+    int shape[2];    // tile shape code of each (64, 32, TILE_32x32, TILE_64x128)
     unsigned gap_in[2], gap_res[2], gap_out[2];  // bytes per share by which the buffer's slices exceed the layer's rows (0: standard layout)
 };
 
@@ -1234,6 +1257,8 @@ __global__ __launch_bounds__(256, 2) void conv_chain_kernel(const ChainStep *ste
                 const ArgsChain a{(ArgsChain::args_ptr)(uintptr_t)&steps[s].a[which], (ArgsChain::gaps_ptr)(uintptr_t)steps[s].gap_in, ws, share, which};
                 if (shape == 64)
                     conv_tile<E, 64, 64, 128 / (int)sizeof(E), 1, false, true>(a, share, slot, lds, nullptr, w);
+                else if (shape == TILE_64x128)
+                    conv_tile<E, 64, 128, 128 / (int)sizeof(E), 1, false, true>(a, share, slot, lds, nullptr, w);
                 else if (shape == 32)
                     conv_tile<E, 32, 64, 256 / (int)sizeof(E), 2, false, true>(a, share, slot, lds, nullptr, w);
                 else
@@ -1339,8 +1364,8 @@ static long max_ktot(const ConvLayer &L) {
 // L.tile names the kernel shape: 128 -> 128x128, 64 -> 64x64, 32 -> 32 rows x 64 columns with the
 // K-tile split over wave pairs, 16 -> 32x32 with the K-tile split over the four waves.
 constexpr int TILE_32x32 = 16;
-static int tile_bm(int tile) { return tile == TILE_32x32 ? 32 : tile; }
-static int tile_bn(int tile) { return tile == 32 ? 64 : tile == TILE_32x32 ? 32 : tile; }
+static int tile_bm(int tile) { return tile == TILE_32x32 ? 32 : tile == TILE_64x128 ? 64 : tile; }
+static int tile_bn(int tile) { return tile == 32 ? 64 : tile == TILE_32x32 ? 32 : tile == TILE_64x128 ? 128 : tile; }
 
 static long m_tiles(const ConvLayer &L, int n_images, int tile) {
     long t = 0;
@@ -1679,6 +1704,18 @@ static int g_chain_min_share_images = [] {
     const char *e = getenv("GDPSO_CHAIN_MIN_SHARE");
     return e && atoi(e) > 0 ? atoi(e) : 1;
 }();
+static bool g_chain_wide = [] {
+    const char *e = getenv("GDPSO_CHAIN_WIDE");  // 0: chain steps keep the planner's 64x64 tiles however many a workgroup gets
+    return e ? e[0] != '0' : true;
+}();
+static int chain_cus() {
+    static int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+        return n;
+    }();
+    return cus;
+}
 int chain_tile(const ConvLayer &L, int n_images, int nshare) {
     if (!dtype_ok(L.dtype) || ceil_div(n_images, nshare) < g_chain_min_share_images) return 0;
     // (a layer planned with 128x128 tiles is long enough to stand alone)
@@ -1726,8 +1763,20 @@ int chain_add(ConvChain *c, const ConvLayer *La, const ChainBuf &in, const Chain
     if (La->dtype != c->dtype || (Lb && Lb->dtype != c->dtype)) return fail(GDPSO_ERR_ARG, "chain: layers of different element types");
     ChainStep st;
     std::memset(&st, 0, sizeof(st));
+    int ta_use = ta, tb_use = tb;
+    if (g_chain_wide) {
+        // more 64x64 tiles than a team has members: the 64-row layers of the step whose width allows it take 64x128
+        const long members = std::max(1, chain_cus() * 2 / 8 / c->nteams);
+        const int share_images = ceil_div(c->n_images, c->nshare());
+        long tiles = m_tiles(*La, share_images, ta) * (La->cout / tile_bn(ta));
+        if (Lb) tiles += m_tiles(*Lb, share_images, tb) * (Lb->cout / tile_bn(tb));
+        if (tiles > members) {
+            if (ta == 64 && La->cout % 128 == 0) ta_use = TILE_64x128;
+            if (Lb && tb == 64 && Lb->cout % 128 == 0) tb_use = TILE_64x128;
+        }
+    }
     c->layers.push_back(*La);
-    c->layers.back().tile = ta;
+    c->layers.back().tile = ta_use;
     c->layers.back().splits = 1;
     int rc = chain_fill(*c, c->layers.back(), in, res, out_a, st, 0);
     if (rc) return rc;
@@ -1735,7 +1784,7 @@ int chain_add(ConvChain *c, const ConvLayer *La, const ChainBuf &in, const Chain
     if (Lb) {
         if (!out_b) return fail(GDPSO_ERR_ARG, "chain: second layer without an output");
         c->layers.push_back(*Lb);
-        c->layers.back().tile = tb;
+        c->layers.back().tile = tb_use;
         c->layers.back().splits = 1;
         if ((rc = chain_fill(*c, c->layers.back(), in, nullptr, *out_b, st, 1))) return rc;
         c->layer_has_res.push_back(0);
