@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgdpso.so")
-SOURCES = ["pack.cpp", "conv_gemm.hip", "nets.hip", "pso.hip", "vq.hip"]
+SOURCES = ["pack.cpp", "conv_gemm.hip", "nets.hip", "stage_resident.hip", "pso.hip", "vq.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 

@@ -170,6 +170,28 @@ int launch_chain(const ConvChain *c, hipStream_t stream, void *workspace, bool c
 // stream this library has launched on on the current device; chains run only while that holds.
 int chain_note_stream(hipStream_t stream, bool *single);
 
+// The batch size launch plans are made for: n_images, or the pinned size of gdpso_plan_options.
+int plan_batch(int n_images);
+// Per-launch timing of convolution kernels (gdpso_conv_timing_begin / _end) for launches made outside
+// conv_gemm.hip: conv_timing_slot hands out the start / stop events of the next timed launch (false: timing
+// is off), conv_timing_account adds what that launch computes and moves.
+bool conv_timing_slot(hipEvent_t *start, hipEvent_t *stop);
+void conv_timing_account(double flops_nominal, double flops_executed, double bytes);
+
+// stage_resident.hip: the first ResNet stage in one launch with its activations resident in LDS
+// (fp32, 7x7 maps, 64 -> 64 -> 256 channel bottlenecks).
+constexpr int RS_MAX_BLOCKS = 4;
+struct ResidentStage;
+struct DeviceArena;
+struct ConvLayer;
+bool resident_stage_enabled();
+int resident_stage_max_images();
+// *out stays null (and GDPSO_OK is returned) when the device cannot run the kernel.
+int resident_stage_new(DeviceArena &arena, int nblocks, const float *const *w, const float *w_ds, const ConvLayer *const *c1,
+                       const ConvLayer *const *c2, const ConvLayer *const *c3, const ConvLayer *ds, ResidentStage **out);
+void resident_stage_free(ResidentStage *s);
+int launch_resident_stage(const ResidentStage *s, hipStream_t stream, int n_images, const float *in, float *out);
+
 // host-side helpers (pack.cpp)
 struct DeviceArena {
     std::vector<void *> blocks;

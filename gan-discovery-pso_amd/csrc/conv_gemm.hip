@@ -1387,8 +1387,23 @@ static bool g_plan_splitk = [] {
     return e ? e[0] != '0' : true;
 }();
 
+int plan_batch(int n_images) { return g_plan_images > 0 ? g_plan_images : n_images; }
+
+bool conv_timing_slot(hipEvent_t *start, hipEvent_t *stop) {
+    if (!g_timing.on || g_timing.used + 2 > g_timing.events.size()) return false;
+    *start = g_timing.events[g_timing.used];
+    *stop = g_timing.events[g_timing.used + 1];
+    g_timing.used += 2;
+    return true;
+}
+void conv_timing_account(double flops_nominal, double flops_executed, double bytes) {
+    g_timing.flops += flops_nominal;
+    g_timing.executed += flops_executed;
+    g_timing.bytes += bytes;
+}
+
 int plan_conv(ConvLayer &L, int n_images, int num_cus) {
-    if (g_plan_images > 0) n_images = g_plan_images;  // shapes as for that batch size, whatever this one is
+    n_images = plan_batch(n_images);  // shapes as for the pinned batch size, whatever this one is
     L.tile = 64;
     if (L.cout % 128 == 0) {
         const long t128 = m_tiles(L, n_images, 128) * (L.cout / 128);

@@ -912,6 +912,9 @@ struct gdpso_assessor {
     const float *stem_w, *stem_scale, *stem_shift;
     std::vector<Bottleneck> blocks;
     int chain_first = 0;  // first block behind the first stage
+    // the first stage as one launch with its activations in LDS (stage_resident.hip), or null: fp32, 7x7 maps
+    ResidentStage *resident = nullptr;
+    ~gdpso_assessor() { resident_stage_free(resident); }
     const float *fc_w, *fc_b;
     int feat_c, feat_hw;
     double flops;
@@ -927,6 +930,7 @@ struct AssLayout {
     // this batch size (null otherwise: a launch per layer)
     ConvChain *chain = nullptr;
     int chain_first = 0;
+    bool resident = false;  // blocks [0, chain_first) through the handle's resident stage at this batch size
     AssLayout() = default;
     AssLayout(const AssLayout &) = delete;
     AssLayout &operator=(const AssLayout &) = delete;
@@ -988,6 +992,7 @@ std::shared_ptr<const AssLayout> ass_layout(const gdpso_assessor *a, int n) {
     // the first stage's output where it lies, keeps its intermediates in per-share slices of y-or-x / z /
     // t1 / t2 / sc and writes the last block's output to a buffer of its own.
     L.chain_first = a->chain_first;
+    L.resident = a->resident != nullptr && plan_batch(n) <= resident_stage_max_images();
     if (a->kind == 0 && chain_enabled() && L.chain_first > 0 && L.chain_first < (int)L.blocks.size()) {
         size_t zmax = 0;
         for (size_t i = L.chain_first; i < L.blocks.size(); ++i) zmax = std::max(zmax, out_elems(L.blocks[i].c3));
@@ -1085,6 +1090,8 @@ extern "C" int gdpso_assessor_create_resnet_typed(gdpso_assessor **out, const in
         a->flops = 2.0 * a->ho * a->ho * 64 * 49;
     }
     int cin = 64, h = a->hp;
+    std::vector<const float *> s1w;  // the first stage's torch weights: conv1, conv2, conv3 per block
+    const float *s1w_ds = nullptr;
     for (int s = 0; s < 4; ++s) {
         const int mid = 64 << s;
         for (int b = 0; b < depths[s]; ++b) {
@@ -1102,6 +1109,12 @@ extern "C" int gdpso_assessor_create_resnet_typed(gdpso_assessor **out, const in
             make_conv(blk.c3, t[ti + 10], mid * 4, mid, 1, 1, 1, 0, h2, h2, ACT_RELU, packed);  // ReLU after the residual add
             fold_bn(mid * 4, nullptr, t[ti + 11], t[ti + 12], t[ti + 13], t[ti + 14], sc, sh);
             if ((rc = upload_conv(a->arena, blk.c3, packed, sc, sh, dtype))) { delete a; return rc; }
+            if (s == 0) {
+                s1w.push_back(t[ti]);
+                s1w.push_back(t[ti + 5]);
+                s1w.push_back(t[ti + 10]);
+                if (b == 0) s1w_ds = t[ti + 15];
+            }
             ti += 15;
             blk.has_ds = (b == 0);
             a->flops += blk.c1.flops_nominal + blk.c2.flops_nominal + blk.c3.flops_nominal;
@@ -1120,6 +1133,16 @@ extern "C" int gdpso_assessor_create_resnet_typed(gdpso_assessor **out, const in
     a->feat_c = cin;
     a->feat_hw = h * h;
     a->chain_first = depths[0];
+    if (dtype == DT_F32 && a->hp == 7 && depths[0] <= RS_MAX_BLOCKS && resident_stage_enabled()) {
+        std::vector<const ConvLayer *> c1, c2, c3;
+        for (int b = 0; b < depths[0]; ++b) {
+            c1.push_back(&a->blocks[b].c1);
+            c2.push_back(&a->blocks[b].c2);
+            c3.push_back(&a->blocks[b].c3);
+        }
+        if ((rc = resident_stage_new(a->arena, depths[0], s1w.data(), s1w_ds, c1.data(), c2.data(), c3.data(), &a->blocks[0].ds,
+                                     &a->resident))) { delete a; return rc; }
+    }
     {
         std::vector<float> w(t[ti], t[ti] + (size_t)n_class * cin), b(t[ti + 1], t[ti + 1] + n_class);
         if ((rc = a->arena.upload(w, &a->fc_w)) || (rc = a->arena.upload(b, &a->fc_b))) { delete a; return rc; }
@@ -1276,6 +1299,9 @@ static int assessor_forward_impl(const gdpso_assessor *a, void *stream_, int n, 
     const bool use_chain = L.chain != nullptr && single_stream;
     f32x4 *const ctl_zero = use_chain ? (f32x4 *)(ws + L.chain_ctl) : nullptr;
     const int ctl_quads = (int)(chain_ctl_bytes() / 16);
+    // The resident first stage reads the stem's output from one buffer and writes the stage's output to the
+    // other; the stem writes where the stage's output does not go (x after an even number of blocks, else y).
+    if (L.resident && L.chain_first % 2 == 0) std::swap(x, y);
     const int mps = (a->side + 6 + 3) / 4 * 4;
     const size_t mfma_smem = ((size_t)(a->side + 6) * mps + (size_t)((a->ho * a->ho + 15) / 16 * 16) * 68) * sizeof(float);
     if (stem_mfma && mfma_smem <= 64 * 1024) {
@@ -1291,8 +1317,13 @@ static int assessor_forward_impl(const gdpso_assessor *a, void *stream_, int n, 
     }
     int rc;
     if ((rc = conv_splitk_prepare(stream, sk))) return rc;
+    if (L.resident) {
+        if ((rc = launch_resident_stage(a->resident, stream, n, (const float *)x, (float *)y))) return rc;
+        std::swap(x, y);
+    }
     for (size_t bi = 0; bi < L.blocks.size(); ++bi) {
         const Bottleneck &b = L.blocks[bi];
+        if (L.resident && (int)bi < L.chain_first) continue;
         if (use_chain && (int)bi >= L.chain_first) {
             if ((int)bi == L.chain_first && (rc = launch_chain(L.chain, stream, workspace, /*ctl_cleared=*/true))) return rc;
             x = ws + L.chain_out;  // (the remaining blocks are all part of the chain)

@@ -1,0 +1,303 @@
+// First ResNet stage with its activations resident in LDS (gfx950, fp32, 7x7 maps).
+//
+// The bottleneck blocks of the first stage (reference src/pso/util_cnn.py:94, 147-157, 160-190: 1x1 -> 3x3 ->
+// 1x1 convolutions with BatchNorm, the projection shortcut of the first block, residual add, ReLU) work on
+// maps of 7x7 pixels when the assessor sees the reference's 28x28 images.  Rows of different images never
+// interact and an image's maps are small: 49 x 256 floats for a block's output, 49 x 64 for the two
+// intermediates.  One workgroup therefore takes TWO images (98 rows = 7 blocks of 16, 150 KB of the CU's
+// 160 KB of LDS), walks every layer of the stage for them and writes only the stage's output: no
+// intermediate touches HBM, nothing is handed between workgroups, and the stage is one launch of n / 2
+// workgroups (one per CU at the 512 particles of the headline configuration) where the tiled kernels
+// need six launches whose tiles of 64 rows come to 1.5 per CU.
+//
+// Arithmetic: v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulation).  The A operand of every
+// layer is read from LDS where the previous layer's epilogue left it (rows padded by 4 floats: conflict-free
+// 16-byte fragment reads); the B operand comes straight from global memory (the stage's weights are 0.85 MB,
+// resident in every L2) in fragment order: the host packs a layer as [column block of 16][k group of 16][lane][4],
+// so a wave's fragment load is one contiguous KiB, prefetched three k groups ahead.  Lane l of a wave holds
+// A[row l & 15][k] and B[k][column l & 15] for the four k = 16 j + 4 (l >> 4) + s of group j: one 16-byte
+// read of each feeds four MFMAs.  The 3x3 convolution reads its nine taps as nine row offsets into the same
+// LDS map; a tap that leaves the image reads a row of zeros.
+//
+// Eight waves: a 64-column layer gives wave w column block w & 3 and every second row block (4 or 3 of the 7);
+// a 256-column layer gives it column blocks 2w, 2w + 1 and all seven row blocks.  Only workgroup barriers
+// between layers.  The sums run over k in another order than the tiled kernels' (groups of 16 interleaved
+// by 4), so the two paths agree to fp32 rounding, not bit for bit; a row's result does not depend on the
+// batch it arrives in nor on its place in the workgroup.
+#include <hip/hip_ext.h>
+
+#include <cstdlib>
+#include <cstring>
+
+#include "common.h"
+
+namespace gdpso {
+
+constexpr int RS_PIX = 49, RS_SIDE = 7, RS_IMAGES = 2, RS_ROWS = RS_PIX * RS_IMAGES;  // 98 rows = 7 blocks of 16
+constexpr int RS_LDX = 256 + 4, RS_LDT = 64 + 4;
+constexpr int RS_ZERO_ROW = RS_ROWS;  // row 98 of the first intermediate: zeros (taps outside the image)
+constexpr int RS_X_FLOATS = RS_ROWS * RS_LDX, RS_T_FLOATS = (RS_ROWS + 1) * RS_LDT;
+constexpr size_t RS_LDS_BYTES = (size_t)(RS_X_FLOATS + 2 * RS_T_FLOATS) * sizeof(float);
+
+struct RsLayer {
+    const float *w;  // [cout / 16][K / 16][64 lanes][4], K = taps * cin in (tap, channel) order
+    const float *scale, *shift;
+};
+struct RsArgs {
+    const float *in;  // [n][49][64]: the stem's output
+    float *out;       // [n][49][256]
+    int n, nblocks;
+    RsLayer ds, c1[RS_MAX_BLOCKS], c2[RS_MAX_BLOCKS], c3[RS_MAX_BLOCKS];
+};
+
+using global_f32x4 = const __attribute__((address_space(1))) f32x4;
+using global_f32 = const __attribute__((address_space(1))) float;
+
+// One layer for one wave: NRB row blocks (rb0, rb0 + RBSTEP, ...) x NCB column blocks (cb0, cb0 + 1, ...),
+// CIN input channels per tap, TAPS = 1 (1x1) or 9 (3x3, padding 1).  A: LDS rows of lda floats; O: LDS rows of
+// ldo floats, also the residual when RES (each lane adds and overwrites its own elements).
+template <int NRB, int RBSTEP, int NCB, int CIN, int TAPS, bool RES, bool RELU>
+__device__ __forceinline__ void rs_layer(const float *__restrict__ A, const int lda, const RsLayer L, const int rb0, const int cb0,
+                                         float *O, const int ldo, const int lane) {
+    constexpr int GPT = CIN / 16, J = TAPS * GPT, PF = 3;
+    const int lrow = lane & 15, lk = lane >> 4;
+    global_f32x4 *bp = (global_f32x4 *)L.w + (size_t)cb0 * J * 64 + lane;
+    f32x4 bq[PF][NCB];
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+        if (p < J) {
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) bq[p][c] = bp[(c * J + p) * 64];
+        }
+    float sc[NCB], sh[NCB];
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) {
+        sc[c] = ((global_f32 *)L.scale)[(cb0 + c) * 16 + lrow];
+        sh[c] = ((global_f32 *)L.shift)[(cb0 + c) * 16 + lrow];
+    }
+    // this lane's A row per row block (rows past the two images repeat the last one; their results are dropped)
+    int arow[NRB], ay[NRB], ax[NRB];
+#pragma unroll
+    for (int i = 0; i < NRB; ++i) {
+        const int row = min((rb0 + i * RBSTEP) * 16 + lrow, RS_ROWS - 1);
+        arow[i] = row;
+        const int p = row >= RS_PIX ? row - RS_PIX : row;
+        ay[i] = (p * 37) >> 8;  // p / 7 for p < 49
+        ax[i] = p - ay[i] * RS_SIDE;
+    }
+    auto a_load = [&](int i, int j) -> f32x4 {
+        const int tap = j / GPT, c0 = (j - tap * GPT) * 16;
+        int row = arow[i];
+        if (TAPS == 9) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            const bool ok = (unsigned)(ay[i] + dy) < (unsigned)RS_SIDE && (unsigned)(ax[i] + dx) < (unsigned)RS_SIDE;
+            row = ok ? row + dy * RS_SIDE + dx : RS_ZERO_ROW;
+        }
+        return *(const f32x4 *)(A + row * lda + c0 + 4 * lk);
+    };
+    f32x4 acc[NRB][NCB];
+#pragma unroll
+    for (int i = 0; i < NRB; ++i)
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) acc[i][c] = 0.f;
+    f32x4 aq[2][NRB];
+#pragma unroll
+    for (int i = 0; i < NRB; ++i) aq[0][i] = a_load(i, 0);
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        if (j + 1 < J) {
+#pragma unroll
+            for (int i = 0; i < NRB; ++i) aq[(j + 1) & 1][i] = a_load(i, j + 1);
+        }
+        f32x4 bcur[NCB];
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) bcur[c] = bq[j % PF][c];
+        if (j + PF < J) {
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) bq[j % PF][c] = bp[(c * J + j + PF) * 64];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < NRB; ++i)
+#pragma unroll
+                for (int c = 0; c < NCB; ++c)
+                    acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[j & 1][i][s], bcur[c][s], acc[i][c], 0, 0, 0);
+    }
+    // epilogue: BatchNorm scale / shift, residual, ReLU; lane holds rows 4 lk + r of column lrow of each block
+#pragma unroll
+    for (int i = 0; i < NRB; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = (rb0 + i * RBSTEP) * 16 + 4 * lk + r;
+            if (row < RS_ROWS) {
+#pragma unroll
+                for (int c = 0; c < NCB; ++c) {
+                    float *o = O + row * ldo + (cb0 + c) * 16 + lrow;
+                    float v = acc[i][c][r] * sc[c] + sh[c];
+                    if (RES) v += *o;
+                    if (RELU) v = fmaxf(v, 0.f);
+                    *o = v;
+                }
+            }
+        }
+}
+
+// A layer of 64 output channels over the whole workgroup (8 waves).
+template <int CIN, int TAPS>
+__device__ __forceinline__ void rs_layer64(const float *A, int lda, const RsLayer L, float *O, int wave, int lane) {
+    if (wave < 4)
+        rs_layer<4, 2, 1, CIN, TAPS, false, true>(A, lda, L, 0, wave & 3, O, RS_LDT, lane);
+    else
+        rs_layer<3, 2, 1, CIN, TAPS, false, true>(A, lda, L, 1, wave & 3, O, RS_LDT, lane);
+}
+
+__global__ __launch_bounds__(512) void stage_resident_kernel(const RsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *X = smem;                    // [98][260]: the block's input / output (256 channels)
+    float *T1 = X + RS_X_FLOATS;        // [99][68]: conv1's output, row 98 zeros
+    float *T2 = T1 + RS_T_FLOATS;       // [99][68]: the stem's output, then conv2's output
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int img0 = blockIdx.x * RS_IMAGES;
+    const int rows = min(RS_IMAGES, a.n - img0) * RS_PIX;
+    {
+        global_f32x4 *src = (global_f32x4 *)(a.in + (size_t)img0 * RS_PIX * 64);
+        for (int i = tid; i < RS_ROWS * 16; i += 512) {
+            const int r = i >> 4, c = (i & 15) * 4;
+            f32x4 v = 0.f;
+            if (r < rows) v = src[i];
+            *(f32x4 *)(T2 + r * RS_LDT + c) = v;
+        }
+        if (tid < 16) *(f32x4 *)(T1 + RS_ZERO_ROW * RS_LDT + tid * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    // first block: conv1 and the projection shortcut read the same input
+    rs_layer64<64, 1>(T2, RS_LDT, a.c1[0], T1, wave, lane);
+    rs_layer<7, 1, 2, 64, 1, false, false>(T2, RS_LDT, a.ds, 0, 2 * wave, X, RS_LDX, lane);
+    __syncthreads();
+    rs_layer64<64, 9>(T1, RS_LDT, a.c2[0], T2, wave, lane);
+    __syncthreads();
+    rs_layer<7, 1, 2, 64, 1, true, true>(T2, RS_LDT, a.c3[0], 0, 2 * wave, X, RS_LDX, lane);
+    __syncthreads();
+    for (int b = 1; b < a.nblocks; ++b) {
+        rs_layer64<256, 1>(X, RS_LDX, a.c1[b], T1, wave, lane);
+        __syncthreads();
+        rs_layer64<64, 9>(T1, RS_LDT, a.c2[b], T2, wave, lane);
+        __syncthreads();
+        rs_layer<7, 1, 2, 64, 1, true, true>(T2, RS_LDT, a.c3[b], 0, 2 * wave, X, RS_LDX, lane);
+        __syncthreads();
+    }
+    {
+        f32x4 *dst = (f32x4 *)(a.out + (size_t)img0 * RS_PIX * 256);
+        for (int i = tid; i < rows * 64; i += 512) {
+            const int r = i >> 6, c = (i & 63) * 4;
+            dst[i] = *(const f32x4 *)(X + r * RS_LDX + c);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ host side
+static bool g_rs_enabled = [] {
+    const char *e = getenv("GDPSO_STAGE1_RESIDENT");
+    return e ? e[0] != '0' : true;
+}();
+// Largest batch (as planned: plan_batch) that takes the resident kernel.  Its workgroups are one per CU
+// and run for the whole stage, so batches of several rounds are better served by the tiled kernels,
+// whose large grids reach a higher fraction of the matrix peak.
+static int g_rs_max_images = [] {
+    const char *e = getenv("GDPSO_STAGE1_RESIDENT_MAX");
+    return e ? atoi(e) : 1024;
+}();
+
+struct ResidentStage {
+    RsArgs args;            // layers filled in, in / out / n per launch
+    double flops, executed, weight_bytes;  // per image (nominal, issued to the matrix cores) and once per launch
+};
+
+bool resident_stage_enabled() { return g_rs_enabled; }
+int resident_stage_max_images() { return g_rs_max_images; }
+void resident_stage_free(ResidentStage *s) { delete s; }
+
+// Packs a torch [cout][cin][kh][kw] weight in the kernel's fragment order.
+static void rs_pack(const float *w, int cout, int cin, int taps, std::vector<float> &out) {
+    const int K = taps * cin, J = K / 16;
+    out.resize((size_t)cout * K);
+    for (int cb = 0; cb < cout / 16; ++cb)
+        for (int j = 0; j < J; ++j)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int s = 0; s < 4; ++s) {
+                    const int co = cb * 16 + (lane & 15), k = 16 * j + 4 * (lane >> 4) + s;
+                    const int tap = k / cin, ci = k - tap * cin;
+                    out[(((size_t)cb * J + j) * 64 + lane) * 4 + s] = w[((size_t)co * cin + ci) * taps + tap];
+                }
+}
+
+// weights: per block conv1, conv2, conv3 torch weights (w[3 b + i]) and the first block's shortcut;
+// layers: the blocks' ConvLayers (their device scale / shift arrays are shared).
+int resident_stage_new(DeviceArena &arena, int nblocks, const float *const *w, const float *w_ds, const ConvLayer *const *c1,
+                       const ConvLayer *const *c2, const ConvLayer *const *c3, const ConvLayer *ds, ResidentStage **out) {
+    *out = nullptr;
+    if (nblocks < 1 || nblocks > RS_MAX_BLOCKS) return GDPSO_OK;  // (not an error: the tiled kernels remain)
+    hipError_t e = hipFuncSetAttribute((const void *)stage_resident_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RS_LDS_BYTES);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return GDPSO_OK;
+    }
+    auto s = new ResidentStage();
+    std::memset(&s->args, 0, sizeof(s->args));
+    s->args.nblocks = nblocks;
+    s->flops = s->executed = s->weight_bytes = 0.0;
+    std::vector<float> packed;
+    int rc = GDPSO_OK;
+    auto add = [&](RsLayer &dst, const float *wt, const ConvLayer *L, int cin, int cout, int taps) {
+        if (rc) return;
+        rs_pack(wt, cout, cin, taps, packed);
+        rc = arena.upload(packed, &dst.w);
+        dst.scale = L->scale;
+        dst.shift = L->shift;
+        s->flops += L->flops_nominal;
+        s->executed += 2.0 * 112 / 2 * cout * cin * taps;  // seven row blocks of 16 for two images
+        s->weight_bytes += 4.0 * cout * cin * taps;
+    };
+    add(s->args.ds, w_ds, ds, 64, 256, 1);
+    for (int b = 0; b < nblocks; ++b) {
+        add(s->args.c1[b], w[3 * b], c1[b], b == 0 ? 64 : 256, 64, 1);
+        add(s->args.c2[b], w[3 * b + 1], c2[b], 64, 64, 9);
+        add(s->args.c3[b], w[3 * b + 2], c3[b], 64, 256, 1);
+    }
+    if (rc) {
+        delete s;
+        return rc;
+    }
+    *out = s;
+    return GDPSO_OK;
+}
+
+int launch_resident_stage(const ResidentStage *s, hipStream_t stream, int n_images, const float *in, float *out) {
+    if (in == out) return fail(GDPSO_ERR_ARG, "resident stage: input and output must be different buffers");
+    RsArgs a = s->args;
+    a.in = in;
+    a.out = out;
+    a.n = n_images;
+    const dim3 grid((unsigned)ceil_div(n_images, RS_IMAGES));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (conv_timing_slot(&e0, &e1)) {
+        hipExtLaunchKernelGGL(stage_resident_kernel, grid, dim3(512), RS_LDS_BYTES, stream, e0, e1, 0, a);
+        conv_timing_account(s->flops * n_images, s->executed * n_images,
+                            s->weight_bytes + 4.0 * n_images * RS_PIX * (64 + 256));
+    } else {
+        hipLaunchKernelGGL(stage_resident_kernel, grid, dim3(512), RS_LDS_BYTES, stream, a);
+    }
+    GDPSO_HIP(hipGetLastError());
+    return GDPSO_OK;
+}
+
+}  // namespace gdpso
+
+extern "C" int gdpso_resident_options(int enabled, int max_images) {
+    using namespace gdpso;
+    GDPSO_REQUIRE(max_images >= 0, "resident_options: max_images must be 0 (keep) or a batch size");
+    g_rs_enabled = enabled != 0;
+    if (max_images > 0) g_rs_max_images = max_images;
+    return GDPSO_OK;
+}

@@ -407,6 +407,16 @@ int gdpso_chain_debug(int enabled, unsigned drop_xcc_mask, int teams);
  * GDPSO_PLAN_SPLITK give the initial values. */
 int gdpso_plan_options(int plan_images, int splitk);
 
+/* No counterpart in the reference: switches of the resident first stage (the bottleneck blocks of the first
+ * ResNet stage, reference src/pso/util_cnn.py:94, 147-157, in ONE launch whose workgroups keep two images'
+ * maps in LDS; fp32 assessors on 28x28 images only).  Applies to assessors created and launch plans made from
+ * now on.  enabled = 0: the first stage runs through the tiled convolution kernels like the other element
+ * types (A/B runs and tests).  max_images > 0: the largest (planned, see gdpso_plan_options) batch that takes
+ * the resident kernel; 0 keeps the current limit (default 1024: larger batches fill the device better with
+ * the tiled kernels).  The two paths add a row's products in different orders and agree to fp32 rounding.
+ * Environment: GDPSO_STAGE1_RESIDENT, GDPSO_STAGE1_RESIDENT_MAX give the initial values. */
+int gdpso_resident_options(int enabled, int max_images);
+
 /* No counterpart in the reference: the tile shape (64, 32 or 16, as in gdpso_conv_probe) a convolution layer
  * would run with as a step of a chained launch over n_images images with `teams` (1 or 2) teams per XCD, or 0
  * when it cannot be a step (fewer than 32 images in a share of the batch, or the layer alone is planned with
