@@ -1141,7 +1141,7 @@ extern "C" int gdpso_assessor_create_resnet_typed(gdpso_assessor **out, const in
             c3.push_back(&a->blocks[b].c3);
         }
         if ((rc = resident_stage_new(a->arena, depths[0], s1w.data(), s1w_ds, c1.data(), c2.data(), c3.data(), &a->blocks[0].ds,
-                                     &a->resident))) { delete a; return rc; }
+                                     a->stem_w, a->stem_scale, a->stem_shift, &a->resident))) { delete a; return rc; }
     }
     {
         std::vector<float> w(t[ti], t[ti] + (size_t)n_class * cin), b(t[ti + 1], t[ti + 1] + n_class);
@@ -1299,12 +1299,15 @@ static int assessor_forward_impl(const gdpso_assessor *a, void *stream_, int n, 
     const bool use_chain = L.chain != nullptr && single_stream;
     f32x4 *const ctl_zero = use_chain ? (f32x4 *)(ws + L.chain_ctl) : nullptr;
     const int ctl_quads = (int)(chain_ctl_bytes() / 16);
-    // The resident first stage reads the stem's output from one buffer and writes the stage's output to the
-    // other; the stem writes where the stage's output does not go (x after an even number of blocks, else y).
-    if (L.resident && L.chain_first % 2 == 0) std::swap(x, y);
     const int mps = (a->side + 6 + 3) / 4 * 4;
     const size_t mfma_smem = ((size_t)(a->side + 6) * mps + (size_t)((a->ho * a->ho + 15) / 16 * 16) * 68) * sizeof(float);
-    if (stem_mfma && mfma_smem <= 64 * 1024) {
+    int rc;
+    if (L.resident) {
+        // stem and first stage in one launch; its output lies where the tiled kernels would have left it (in x
+        // after an even number of blocks, else in y)
+        if (L.chain_first % 2 == 1) std::swap(x, y);
+        if ((rc = launch_resident_stage(a->resident, stream, n, img01, (float *)x, ctl_zero, ctl_quads))) return rc;
+    } else if (stem_mfma && mfma_smem <= 64 * 1024) {
         GDPSO_WITH_DTYPE(a->dtype, hipLaunchKernelGGL(stem_mfma_kernel<E>, dim3(n), dim3(512), mfma_smem, stream, img01, a->stem_w,
                                                       a->stem_scale, a->stem_shift, a->side, a->ho, a->hp, mps,
                                                       fast_div_for((unsigned)a->ho), fast_div_for((unsigned)a->hp), (E *)x, ctl_zero, ctl_quads));
@@ -1315,12 +1318,7 @@ static int assessor_forward_impl(const gdpso_assessor *a, void *stream_, int n, 
         GDPSO_WITH_DTYPE(a->dtype, hipLaunchKernelGGL(stem_kernel<E>, grid, dim3(512), smem, stream, img01, a->stem_w, a->stem_scale,
                                                       a->stem_shift, a->side, a->ho, a->hp, a->stem_band, a->stem_ps, (E *)x, ctl_zero, ctl_quads));
     }
-    int rc;
     if ((rc = conv_splitk_prepare(stream, sk))) return rc;
-    if (L.resident) {
-        if ((rc = launch_resident_stage(a->resident, stream, n, (const float *)x, (float *)y))) return rc;
-        std::swap(x, y);
-    }
     for (size_t bi = 0; bi < L.blocks.size(); ++bi) {
         const Bottleneck &b = L.blocks[bi];
         if (L.resident && (int)bi < L.chain_first) continue;

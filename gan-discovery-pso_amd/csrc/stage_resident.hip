@@ -44,9 +44,12 @@ struct RsLayer {
     const float *scale, *shift;
 };
 struct RsArgs {
-    const float *in;  // [n][49][64]: the stem's output
-    float *out;       // [n][49][256]
+    const float *img01;  // [n][28][28]: the images the assessor sees
+    float *out;          // [n][49][256]
     int n, nblocks;
+    const float *stem_w, *stem_scale, *stem_shift;  // [49][64] (tap-major), [64], [64]
+    f32x4 *zero;         // 16-byte words this launch clears on its way (the control block of the chained launch behind it), or null
+    int zero_quads;
     RsLayer ds, c1[RS_MAX_BLOCKS], c2[RS_MAX_BLOCKS], c3[RS_MAX_BLOCKS];
 };
 
@@ -152,24 +155,105 @@ __device__ __forceinline__ void rs_layer64(const float *A, int lda, const RsLaye
         rs_layer<3, 2, 1, CIN, TAPS, false, true>(A, lda, L, 1, wave & 3, O, RS_LDT, lane);
 }
 
+// The stem for the workgroup's two images: Conv2d(1 -> 64, k7, s2, p3, no bias) + BatchNorm + ReLU + MaxPool2d(3, s2, p1)
+// (reference src/pso/util_cnn.py:85-88, 103-106), 28x28 -> 14x14 -> 7x7.  Per image the convolution is a 196 x 64 x 49
+// product on v_mfma_f32_16x16x4_f32 with the operand order of stem_mfma_kernel (nets.hip; bit-identical to it): A
+// gathered from the zero-padded image in LDS, lane l holding A[row l & 15][k = 4 t + (l >> 4)] and B[that k][column
+// l & 15] at step t, K padded to 52 with zero weights.  The convolution images (2 x 208 rows x 68 floats) lie where
+// the 256-channel map and the first intermediate will be; padded images and staged weights where the pooled result
+// goes once they are dead.
+constexpr int ST_SIDE = 28, ST_HO = 14, ST_NPX = ST_HO * ST_HO, ST_NBLK = (ST_NPX + 15) / 16, ST_PROWS = ST_SIDE + 6, ST_PS = 36;
+constexpr int ST_LDC = 68, ST_LDW = 80, ST_KSTEPS = 13, ST_IMG_FLOATS = ST_PROWS * ST_PS;
+static_assert(RS_IMAGES * ST_NBLK * 16 * ST_LDC <= RS_X_FLOATS + RS_ZERO_ROW * RS_LDT, "convolution images overlap the zero row");
+static_assert(RS_IMAGES * ST_IMG_FLOATS + 49 * ST_LDW <= RS_T_FLOATS, "padded images and staged weights exceed the second intermediate");
+
+__device__ __forceinline__ void rs_stem(const RsArgs &a, float *smem, float *T2, int img0, int nimg, int tid) {
+    const int lane = tid & 63, wave = tid >> 6, lrow = lane & 15, lk = lane >> 4;
+    float *s_conv = smem;                              // [2][208][68]
+    float *s_img = T2;                                 // [2][34][36], zero border of 3
+    float *s_w = T2 + RS_IMAGES * ST_IMG_FLOATS;       // [49][80]
+    for (int i = tid; i < RS_IMAGES * ST_IMG_FLOATS; i += 512) {
+        const int im = i / ST_IMG_FLOATS, q = i - im * ST_IMG_FLOATS, row = q / ST_PS, col = q - row * ST_PS;
+        const int y = row - 3, x = col - 3;
+        float v = 0.f;
+        if (im < nimg && (unsigned)y < (unsigned)ST_SIDE && (unsigned)x < (unsigned)ST_SIDE)
+            v = ((global_f32 *)a.img01)[(size_t)(img0 + im) * ST_SIDE * ST_SIDE + y * ST_SIDE + x];
+        s_img[i] = v;
+    }
+    for (int i = tid; i < 49 * 16; i += 512) {
+        const int k = i >> 4, c = (i & 15) * 4;
+        *(f32x4 *)&s_w[k * ST_LDW + c] = *(global_f32x4 *)&a.stem_w[k * 64 + c];
+    }
+    float sc[4], sh[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        sc[cb] = ((global_f32 *)a.stem_scale)[cb * 16 + lrow];
+        sh[cb] = ((global_f32 *)a.stem_shift)[cb * 16 + lrow];
+    }
+    __syncthreads();
+    int koff[ST_KSTEPS];
+    float bw[ST_KSTEPS][4];
+#pragma unroll
+    for (int t = 0; t < ST_KSTEPS; ++t) {
+        const int k = 4 * t + lk;
+        const int kk = k < 49 ? k : 0;
+        koff[t] = (kk / 7) * ST_PS + kk % 7;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) bw[t][cb] = k < 49 ? s_w[k * ST_LDW + cb * 16 + lrow] : 0.f;
+    }
+    for (int b = wave; b < RS_IMAGES * ST_NBLK; b += 8) {
+        const int im = b >= ST_NBLK ? 1 : 0, bb = b - im * ST_NBLK;
+        const int px = min(bb * 16 + lrow, ST_NPX - 1);  // rows past the image repeat the last pixel; they are never read back
+        const int y = px / ST_HO, x = px - y * ST_HO;
+        const float *base = s_img + im * ST_IMG_FLOATS + (2 * y) * ST_PS + 2 * x;  // padded coordinates: +3 - 3
+        float av[ST_KSTEPS];
+#pragma unroll
+        for (int t = 0; t < ST_KSTEPS; ++t) av[t] = base[koff[t]];
+        f32x4 acc[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) acc[cb] = 0.f;
+#pragma unroll
+        for (int t = 0; t < ST_KSTEPS; ++t)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bw[t][cb], acc[cb], 0, 0, 0);
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                s_conv[(b * 16 + 4 * lk + r) * ST_LDC + cb * 16 + lrow] = fmaxf(acc[cb][r] * sc[cb] + sh[cb], 0.f);
+    }
+    __syncthreads();
+    // MaxPool2d(3, s2, p1) into the rows of the first block's input; consecutive threads take consecutive channels
+    for (int e = tid; e < RS_ROWS * 64; e += 512) {
+        const int c = e & 63, pp = e >> 6, im = pp >= RS_PIX ? 1 : 0, p = pp - im * RS_PIX, pr = (p * 37) >> 8, pc = p - pr * RS_SIDE;
+        float m = -INFINITY;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int cy = 2 * pr + dy;
+            if ((unsigned)cy >= (unsigned)ST_HO) continue;
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int cx = 2 * pc + dx;
+                if ((unsigned)cx >= (unsigned)ST_HO) continue;
+                m = fmaxf(m, s_conv[(im * ST_NBLK * 16 + cy * ST_HO + cx) * ST_LDC + c]);
+            }
+        }
+        T2[pp * RS_LDT + c] = m;
+    }
+}
+
 __global__ __launch_bounds__(512) void stage_resident_kernel(const RsArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *X = smem;                    // [98][260]: the block's input / output (256 channels)
     float *T1 = X + RS_X_FLOATS;        // [99][68]: conv1's output, row 98 zeros
-    float *T2 = T1 + RS_T_FLOATS;       // [99][68]: the stem's output, then conv2's output
+    float *T2 = T1 + RS_T_FLOATS;       // [99][68]: the stem's (pooled) output, then conv2's output
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int img0 = blockIdx.x * RS_IMAGES;
-    const int rows = min(RS_IMAGES, a.n - img0) * RS_PIX;
-    {
-        global_f32x4 *src = (global_f32x4 *)(a.in + (size_t)img0 * RS_PIX * 64);
-        for (int i = tid; i < RS_ROWS * 16; i += 512) {
-            const int r = i >> 4, c = (i & 15) * 4;
-            f32x4 v = 0.f;
-            if (r < rows) v = src[i];
-            *(f32x4 *)(T2 + r * RS_LDT + c) = v;
-        }
-        if (tid < 16) *(f32x4 *)(T1 + RS_ZERO_ROW * RS_LDT + tid * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    const int nimg = min(RS_IMAGES, a.n - img0), rows = nimg * RS_PIX;
+    if (a.zero != nullptr)
+        for (int i = blockIdx.x * 512 + tid; i < a.zero_quads; i += gridDim.x * 512) a.zero[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < 16) *(f32x4 *)(T1 + RS_ZERO_ROW * RS_LDT + tid * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    rs_stem(a, smem, T2, img0, nimg, tid);
     __syncthreads();
     // first block: conv1 and the projection shortcut read the same input
     rs_layer64<64, 1>(T2, RS_LDT, a.c1[0], T1, wave, lane);
@@ -235,7 +319,8 @@ static void rs_pack(const float *w, int cout, int cin, int taps, std::vector<flo
 // weights: per block conv1, conv2, conv3 torch weights (w[3 b + i]) and the first block's shortcut;
 // layers: the blocks' ConvLayers (their device scale / shift arrays are shared).
 int resident_stage_new(DeviceArena &arena, int nblocks, const float *const *w, const float *w_ds, const ConvLayer *const *c1,
-                       const ConvLayer *const *c2, const ConvLayer *const *c3, const ConvLayer *ds, ResidentStage **out) {
+                       const ConvLayer *const *c2, const ConvLayer *const *c3, const ConvLayer *ds, const float *stem_w,
+                       const float *stem_scale, const float *stem_shift, ResidentStage **out) {
     *out = nullptr;
     if (nblocks < 1 || nblocks > RS_MAX_BLOCKS) return GDPSO_OK;  // (not an error: the tiled kernels remain)
     hipError_t e = hipFuncSetAttribute((const void *)stage_resident_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RS_LDS_BYTES);
@@ -246,7 +331,13 @@ int resident_stage_new(DeviceArena &arena, int nblocks, const float *const *w, c
     auto s = new ResidentStage();
     std::memset(&s->args, 0, sizeof(s->args));
     s->args.nblocks = nblocks;
-    s->flops = s->executed = s->weight_bytes = 0.0;
+    s->args.stem_w = stem_w;
+    s->args.stem_scale = stem_scale;
+    s->args.stem_shift = stem_shift;
+    // the stem: 196 pixels x 64 channels x 49 taps per image (13 row blocks of 16, K padded to 52, on the matrix cores)
+    s->flops = 2.0 * ST_NPX * 64 * 49;
+    s->executed = 2.0 * ST_NBLK * 16 * 64 * 4 * ST_KSTEPS;
+    s->weight_bytes = 4.0 * 49 * 64;
     std::vector<float> packed;
     int rc = GDPSO_OK;
     auto add = [&](RsLayer &dst, const float *wt, const ConvLayer *L, int cin, int cout, int taps) {
@@ -273,18 +364,20 @@ int resident_stage_new(DeviceArena &arena, int nblocks, const float *const *w, c
     return GDPSO_OK;
 }
 
-int launch_resident_stage(const ResidentStage *s, hipStream_t stream, int n_images, const float *in, float *out) {
-    if (in == out) return fail(GDPSO_ERR_ARG, "resident stage: input and output must be different buffers");
+int launch_resident_stage(const ResidentStage *s, hipStream_t stream, int n_images, const float *img01, float *out, void *zero,
+                          int zero_quads) {
     RsArgs a = s->args;
-    a.in = in;
+    a.img01 = img01;
     a.out = out;
     a.n = n_images;
+    a.zero = (f32x4 *)zero;
+    a.zero_quads = zero_quads;
     const dim3 grid((unsigned)ceil_div(n_images, RS_IMAGES));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (conv_timing_slot(&e0, &e1)) {
         hipExtLaunchKernelGGL(stage_resident_kernel, grid, dim3(512), RS_LDS_BYTES, stream, e0, e1, 0, a);
         conv_timing_account(s->flops * n_images, s->executed * n_images,
-                            s->weight_bytes + 4.0 * n_images * RS_PIX * (64 + 256));
+                            s->weight_bytes + 4.0 * n_images * (ST_SIDE * ST_SIDE + RS_PIX * 256));
     } else {
         hipLaunchKernelGGL(stage_resident_kernel, grid, dim3(512), RS_LDS_BYTES, stream, a);
     }
