@@ -108,6 +108,9 @@ __device__ __forceinline__ void rs_layer(const float *__restrict__ A, const int 
     for (int i = 0; i < NRB; ++i) aq[0][i] = a_load(i, 0);
 #pragma unroll
     for (int j = 0; j < J; ++j) {
+        // (the scheduler may not move anything across a group's border: left alone it sinks the fragment loads
+        // to just ahead of their first use, which undoes the prefetch distance)
+        __builtin_amdgcn_sched_barrier(0);
         if (j + 1 < J) {
 #pragma unroll
             for (int i = 0; i < NRB; ++i) aq[(j + 1) & 1][i] = a_load(i, j + 1);
