@@ -179,7 +179,7 @@ bool conv_timing_slot(hipEvent_t *start, hipEvent_t *stop);
 void conv_timing_account(double flops_nominal, double flops_executed, double bytes);
 
 // stage_resident.hip: the stem and the first ResNet stage in one launch with the activations resident in LDS
-// (fp32, 28x28 images, 7x7 maps, 64 -> 64 -> 256 channel bottlenecks).
+// (28x28 images, 7x7 maps, 64 -> 64 -> 256 channel bottlenecks; any of the three element types).
 constexpr int RS_MAX_BLOCKS = 4;
 struct ResidentStage;
 struct DeviceArena;
@@ -187,12 +187,12 @@ struct ConvLayer;
 bool resident_stage_enabled();
 int resident_stage_max_images();
 // *out stays null (and GDPSO_OK is returned) when the device cannot run the kernel.
-int resident_stage_new(DeviceArena &arena, int nblocks, const float *const *w, const float *w_ds, const ConvLayer *const *c1,
+int resident_stage_new(DeviceArena &arena, int dtype, int nblocks, const float *const *w, const float *w_ds, const ConvLayer *const *c1,
                        const ConvLayer *const *c2, const ConvLayer *const *c3, const ConvLayer *ds, const float *stem_w,
                        const float *stem_scale, const float *stem_shift, ResidentStage **out);
 void resident_stage_free(ResidentStage *s);
 // img01: the [n][28][28] images; out: the stage's NHWC output; zero / zero_quads: 16-byte words the launch clears on its way.
-int launch_resident_stage(const ResidentStage *s, hipStream_t stream, int n_images, const float *img01, float *out, void *zero,
+int launch_resident_stage(const ResidentStage *s, hipStream_t stream, int n_images, const float *img01, void *out, void *zero,
                           int zero_quads);
 
 // host-side helpers (pack.cpp)

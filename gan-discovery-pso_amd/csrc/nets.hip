@@ -912,7 +912,7 @@ struct gdpso_assessor {
     const float *stem_w, *stem_scale, *stem_shift;
     std::vector<Bottleneck> blocks;
     int chain_first = 0;  // first block behind the first stage
-    // the first stage as one launch with its activations in LDS (stage_resident.hip), or null: fp32, 7x7 maps
+    // stem and first stage as one launch with the activations in LDS (stage_resident.hip), or null: 28x28 images only
     ResidentStage *resident = nullptr;
     ~gdpso_assessor() { resident_stage_free(resident); }
     const float *fc_w, *fc_b;
@@ -1133,14 +1133,14 @@ extern "C" int gdpso_assessor_create_resnet_typed(gdpso_assessor **out, const in
     a->feat_c = cin;
     a->feat_hw = h * h;
     a->chain_first = depths[0];
-    if (dtype == DT_F32 && a->hp == 7 && depths[0] <= RS_MAX_BLOCKS && resident_stage_enabled()) {
+    if (img_side == 28 && depths[0] <= RS_MAX_BLOCKS && resident_stage_enabled()) {
         std::vector<const ConvLayer *> c1, c2, c3;
         for (int b = 0; b < depths[0]; ++b) {
             c1.push_back(&a->blocks[b].c1);
             c2.push_back(&a->blocks[b].c2);
             c3.push_back(&a->blocks[b].c3);
         }
-        if ((rc = resident_stage_new(a->arena, depths[0], s1w.data(), s1w_ds, c1.data(), c2.data(), c3.data(), &a->blocks[0].ds,
+        if ((rc = resident_stage_new(a->arena, dtype, depths[0], s1w.data(), s1w_ds, c1.data(), c2.data(), c3.data(), &a->blocks[0].ds,
                                      a->stem_w, a->stem_scale, a->stem_shift, &a->resident))) { delete a; return rc; }
     }
     {
@@ -1306,7 +1306,7 @@ static int assessor_forward_impl(const gdpso_assessor *a, void *stream_, int n, 
         // stem and first stage in one launch; its output lies where the tiled kernels would have left it (in x
         // after an even number of blocks, else in y)
         if (L.chain_first % 2 == 1) std::swap(x, y);
-        if ((rc = launch_resident_stage(a->resident, stream, n, img01, (float *)x, ctl_zero, ctl_quads))) return rc;
+        if ((rc = launch_resident_stage(a->resident, stream, n, img01, x, ctl_zero, ctl_quads))) return rc;
     } else if (stem_mfma && mfma_smem <= 64 * 1024) {
         GDPSO_WITH_DTYPE(a->dtype, hipLaunchKernelGGL(stem_mfma_kernel<E>, dim3(n), dim3(512), mfma_smem, stream, img01, a->stem_w,
                                                       a->stem_scale, a->stem_shift, a->side, a->ho, a->hp, mps,

@@ -24,6 +24,11 @@
 // between layers.  The sums run over k in another order than the tiled kernels' (groups of 16 interleaved
 // by 4), so the two paths agree to fp32 rounding, not bit for bit; a row's result does not depend on the
 // batch it arrives in nor on its place in the workgroup.
+//
+// 16-bit storage (bf16 / fp16): the same kernel with v_mfma_f32_16x16x32_bf16 / _f16; a 16-byte fragment is then
+// eight consecutive k of ONE instruction (a k group is 32 wide), LDS rows are padded by 8 elements, accumulation,
+// BatchNorm, residual add and ReLU stay fp32 and a layer's result is rounded once on its way to LDS, as the
+// tiled kernels round it on its way to memory.
 #include <hip/hip_ext.h>
 
 #include <cstdlib>
@@ -34,18 +39,42 @@
 namespace gdpso {
 
 constexpr int RS_PIX = 49, RS_SIDE = 7, RS_IMAGES = 2, RS_ROWS = RS_PIX * RS_IMAGES;  // 98 rows = 7 blocks of 16
-constexpr int RS_LDX = 256 + 4, RS_LDT = 64 + 4;
 constexpr int RS_ZERO_ROW = RS_ROWS;  // row 98 of the first intermediate: zeros (taps outside the image)
-constexpr int RS_X_FLOATS = RS_ROWS * RS_LDX, RS_T_FLOATS = (RS_ROWS + 1) * RS_LDT;
-constexpr size_t RS_LDS_BYTES = (size_t)(RS_X_FLOATS + 2 * RS_T_FLOATS) * sizeof(float);
+// The stem's scratch, floats whatever the element type: convolution images [2][208][68], padded images [2][34][36],
+// staged weights [49][80].
+constexpr int ST_SIDE = 28, ST_HO = 14, ST_NPX = ST_HO * ST_HO, ST_NBLK = (ST_NPX + 15) / 16, ST_PROWS = ST_SIDE + 6, ST_PS = 36;
+constexpr int ST_LDC = 68, ST_LDW = 80, ST_KSTEPS = 13, ST_IMG_FLOATS = ST_PROWS * ST_PS;
+constexpr size_t ST_CONV_BYTES = (size_t)RS_IMAGES * ST_NBLK * 16 * ST_LDC * 4, ST_IN_BYTES = (size_t)(RS_IMAGES * ST_IMG_FLOATS + 49 * ST_LDW) * 4;
+
+// LDS layout of one element type.  X: the block's input / output [98][256 + pad]; T1: conv1's output [99][64 + pad]
+// (row 98 zeros); T2: the pooled stem output, then conv2's output [99][64 + pad].  Rows are padded by 16 bytes:
+// the 16-byte fragment reads of eight consecutive rows then fall into different banks.  The stem's convolution
+// images lie over X and T1 (and must end ahead of T2, which the pooling writes while it reads them); its padded
+// images and staged weights lie in T2 where T2 is large enough (fp32: the pooling overwrites them when they are
+// dead) and behind T2 otherwise.
+template <typename E>
+struct RsLds {
+    static constexpr int VEC = 16 / (int)sizeof(E);     // elements of a 16-byte fragment
+    static constexpr int KG = is_f32<E>() ? 16 : 32;     // k of one group: four fp32 MFMAs of 4, or one 16-bit MFMA of 32
+    static constexpr int LDX = 256 + VEC, LDT = 64 + VEC;
+    static constexpr size_t X_BYTES = (size_t)RS_ROWS * LDX * sizeof(E), T_BYTES = (size_t)(RS_ROWS + 1) * LDT * sizeof(E);
+    static constexpr size_t T1_OFF = X_BYTES;
+    static constexpr size_t T2_OFF = X_BYTES + T_BYTES > ST_CONV_BYTES ? X_BYTES + T_BYTES : ST_CONV_BYTES;
+    static constexpr size_t ST_IN_OFF = T_BYTES >= ST_IN_BYTES ? T2_OFF : T2_OFF + T_BYTES;
+    static constexpr size_t BYTES = ST_IN_OFF + ST_IN_BYTES > T2_OFF + T_BYTES ? ST_IN_OFF + ST_IN_BYTES : T2_OFF + T_BYTES;
+    static_assert(ST_CONV_BYTES <= T2_OFF && ST_CONV_BYTES <= ST_IN_OFF, "the stem's convolution images overlap what is written while they are read");
+    static_assert(T1_OFF % 16 == 0 && T2_OFF % 16 == 0 && ST_IN_OFF % 16 == 0 && BYTES <= 160 * 1024, "LDS layout");
+};
 
 struct RsLayer {
-    const float *w;  // [cout / 16][K / 16][64 lanes][4], K = taps * cin in (tap, channel) order
+    // weights in fragment order, elements of the network's type: [cout / 16][K / KG][64 lanes][VEC],
+    // K = taps * cin in (tap, channel) order, lane l = column l & 15, k = KG * group + VEC * (l >> 4) + (0 .. VEC - 1)
+    const void *w;
     const float *scale, *shift;
 };
 struct RsArgs {
     const float *img01;  // [n][28][28]: the images the assessor sees
-    float *out;          // [n][49][256]
+    void *out;           // [n][49][256], elements of the network's type
     int n, nblocks;
     const float *stem_w, *stem_scale, *stem_shift;  // [49][64] (tap-major), [64], [64]
     f32x4 *zero;         // 16-byte words this launch clears on its way (the control block of the chained launch behind it), or null
@@ -53,16 +82,32 @@ struct RsArgs {
     RsLayer ds, c1[RS_MAX_BLOCKS], c2[RS_MAX_BLOCKS], c3[RS_MAX_BLOCKS];
 };
 
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+// One k group of one 16x16 block: a, b are the lane's 16-byte fragments.
+template <typename E>
+__device__ __forceinline__ f32x4 rs_mfma(const f32x4 &a, const f32x4 &b, f32x4 c) {
+    if constexpr (is_f32<E>()) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], c, 0, 0, 0);
+        return c;
+    } else if constexpr (__is_same(E, bf16_t)) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    } else {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+}
+
 using global_f32x4 = const __attribute__((address_space(1))) f32x4;
 using global_f32 = const __attribute__((address_space(1))) float;
 
 // One layer for one wave: NRB row blocks (rb0, rb0 + RBSTEP, ...) x NCB column blocks (cb0, cb0 + 1, ...),
-// CIN input channels per tap, TAPS = 1 (1x1) or 9 (3x3, padding 1).  A: LDS rows of lda floats; O: LDS rows of
-// ldo floats, also the residual when RES (each lane adds and overwrites its own elements).
-template <int NRB, int RBSTEP, int NCB, int CIN, int TAPS, bool RES, bool RELU>
-__device__ __forceinline__ void rs_layer(const float *__restrict__ A, const int lda, const RsLayer L, const int rb0, const int cb0,
-                                         float *O, const int ldo, const int lane) {
-    constexpr int GPT = CIN / 16, J = TAPS * GPT, PF = 3;
+// CIN input channels per tap, TAPS = 1 (1x1) or 9 (3x3, padding 1).  A: LDS rows of lda elements; O: LDS rows of
+// ldo elements, also the residual when RES (each lane adds and overwrites its own elements).
+template <typename E, int NRB, int RBSTEP, int NCB, int CIN, int TAPS, bool RES, bool RELU>
+__device__ __forceinline__ void rs_layer(const E *__restrict__ A, const int lda, const RsLayer L, const int rb0, const int cb0,
+                                         E *O, const int ldo, const int lane) {
+    constexpr int VEC = RsLds<E>::VEC, KG = RsLds<E>::KG, GPT = CIN / KG, J = TAPS * GPT, PF = 3;
     const int lrow = lane & 15, lk = lane >> 4;
     global_f32x4 *bp = (global_f32x4 *)L.w + (size_t)cb0 * J * 64 + lane;
     f32x4 bq[PF][NCB];
@@ -89,14 +134,14 @@ __device__ __forceinline__ void rs_layer(const float *__restrict__ A, const int 
         ax[i] = p - ay[i] * RS_SIDE;
     }
     auto a_load = [&](int i, int j) -> f32x4 {
-        const int tap = j / GPT, c0 = (j - tap * GPT) * 16;
+        const int tap = j / GPT, c0 = (j - tap * GPT) * KG;
         int row = arow[i];
         if (TAPS == 9) {
             const int dy = tap / 3 - 1, dx = tap % 3 - 1;
             const bool ok = (unsigned)(ay[i] + dy) < (unsigned)RS_SIDE && (unsigned)(ax[i] + dx) < (unsigned)RS_SIDE;
             row = ok ? row + dy * RS_SIDE + dx : RS_ZERO_ROW;
         }
-        return *(const f32x4 *)(A + row * lda + c0 + 4 * lk);
+        return *(const f32x4 *)(A + row * lda + c0 + VEC * lk);
     };
     f32x4 acc[NRB][NCB];
 #pragma unroll
@@ -122,13 +167,20 @@ __device__ __forceinline__ void rs_layer(const float *__restrict__ A, const int 
 #pragma unroll
             for (int c = 0; c < NCB; ++c) bq[j % PF][c] = bp[(c * J + j + PF) * 64];
         }
+        if constexpr (is_f32<E>()) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < NRB; ++i)
+#pragma unroll
+                    for (int c = 0; c < NCB; ++c)
+                        acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[j & 1][i][s], bcur[c][s], acc[i][c], 0, 0, 0);
+        } else {
 #pragma unroll
             for (int i = 0; i < NRB; ++i)
 #pragma unroll
-                for (int c = 0; c < NCB; ++c)
-                    acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[j & 1][i][s], bcur[c][s], acc[i][c], 0, 0, 0);
+                for (int c = 0; c < NCB; ++c) acc[i][c] = rs_mfma<E>(aq[j & 1][i], bcur[c], acc[i][c]);
+        }
     }
     // epilogue: BatchNorm scale / shift, residual, ReLU; lane holds rows 4 lk + r of column lrow of each block
 #pragma unroll
@@ -139,23 +191,23 @@ __device__ __forceinline__ void rs_layer(const float *__restrict__ A, const int 
             if (row < RS_ROWS) {
 #pragma unroll
                 for (int c = 0; c < NCB; ++c) {
-                    float *o = O + row * ldo + (cb0 + c) * 16 + lrow;
+                    E *o = O + row * ldo + (cb0 + c) * 16 + lrow;
                     float v = acc[i][c][r] * sc[c] + sh[c];
-                    if (RES) v += *o;
+                    if (RES) v += (float)*o;
                     if (RELU) v = fmaxf(v, 0.f);
-                    *o = v;
+                    *o = (E)v;
                 }
             }
         }
 }
 
 // A layer of 64 output channels over the whole workgroup (8 waves).
-template <int CIN, int TAPS>
-__device__ __forceinline__ void rs_layer64(const float *A, int lda, const RsLayer L, float *O, int wave, int lane) {
+template <typename E, int CIN, int TAPS>
+__device__ __forceinline__ void rs_layer64(const E *A, int lda, const RsLayer L, E *O, int wave, int lane) {
     if (wave < 4)
-        rs_layer<4, 2, 1, CIN, TAPS, false, true>(A, lda, L, 0, wave & 3, O, RS_LDT, lane);
+        rs_layer<E, 4, 2, 1, CIN, TAPS, false, true>(A, lda, L, 0, wave & 3, O, RsLds<E>::LDT, lane);
     else
-        rs_layer<3, 2, 1, CIN, TAPS, false, true>(A, lda, L, 1, wave & 3, O, RS_LDT, lane);
+        rs_layer<E, 3, 2, 1, CIN, TAPS, false, true>(A, lda, L, 1, wave & 3, O, RsLds<E>::LDT, lane);
 }
 
 // The stem for the workgroup's two images: Conv2d(1 -> 64, k7, s2, p3, no bias) + BatchNorm + ReLU + MaxPool2d(3, s2, p1)
@@ -164,17 +216,13 @@ __device__ __forceinline__ void rs_layer64(const float *A, int lda, const RsLaye
 // gathered from the zero-padded image in LDS, lane l holding A[row l & 15][k = 4 t + (l >> 4)] and B[that k][column
 // l & 15] at step t, K padded to 52 with zero weights.  The convolution images (2 x 208 rows x 68 floats) lie where
 // the 256-channel map and the first intermediate will be; padded images and staged weights where the pooled result
-// goes once they are dead.
-constexpr int ST_SIDE = 28, ST_HO = 14, ST_NPX = ST_HO * ST_HO, ST_NBLK = (ST_NPX + 15) / 16, ST_PROWS = ST_SIDE + 6, ST_PS = 36;
-constexpr int ST_LDC = 68, ST_LDW = 80, ST_KSTEPS = 13, ST_IMG_FLOATS = ST_PROWS * ST_PS;
-static_assert(RS_IMAGES * ST_NBLK * 16 * ST_LDC <= RS_X_FLOATS + RS_ZERO_ROW * RS_LDT, "convolution images overlap the zero row");
-static_assert(RS_IMAGES * ST_IMG_FLOATS + 49 * ST_LDW <= RS_T_FLOATS, "padded images and staged weights exceed the second intermediate");
-
-__device__ __forceinline__ void rs_stem(const RsArgs &a, float *smem, float *T2, int img0, int nimg, int tid) {
+// goes once they are dead (see RsLds).
+template <typename E>
+__device__ __forceinline__ void rs_stem(const RsArgs &a, char *smem, E *T2, int img0, int nimg, int tid) {
     const int lane = tid & 63, wave = tid >> 6, lrow = lane & 15, lk = lane >> 4;
-    float *s_conv = smem;                              // [2][208][68]
-    float *s_img = T2;                                 // [2][34][36], zero border of 3
-    float *s_w = T2 + RS_IMAGES * ST_IMG_FLOATS;       // [49][80]
+    float *s_conv = (float *)smem;                            // [2][208][68]
+    float *s_img = (float *)(smem + RsLds<E>::ST_IN_OFF);     // [2][34][36], zero border of 3
+    float *s_w = s_img + RS_IMAGES * ST_IMG_FLOATS;           // [49][80]
     for (int i = tid; i < RS_IMAGES * ST_IMG_FLOATS; i += 512) {
         const int im = i / ST_IMG_FLOATS, q = i - im * ST_IMG_FLOATS, row = q / ST_PS, col = q - row * ST_PS;
         const int y = row - 3, x = col - 3;
@@ -241,44 +289,49 @@ __device__ __forceinline__ void rs_stem(const RsArgs &a, float *smem, float *T2,
                 m = fmaxf(m, s_conv[(im * ST_NBLK * 16 + cy * ST_HO + cx) * ST_LDC + c]);
             }
         }
-        T2[pp * RS_LDT + c] = m;
+        T2[pp * RsLds<E>::LDT + c] = (E)m;
     }
 }
 
+template <typename E>
 __global__ __launch_bounds__(512) void stage_resident_kernel(const RsArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *X = smem;                    // [98][260]: the block's input / output (256 channels)
-    float *T1 = X + RS_X_FLOATS;        // [99][68]: conv1's output, row 98 zeros
-    float *T2 = T1 + RS_T_FLOATS;       // [99][68]: the stem's (pooled) output, then conv2's output
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using LY = RsLds<E>;
+    constexpr int LDX = LY::LDX, LDT = LY::LDT;
+    E *X = (E *)smem;                    // [98][LDX]: the block's input / output (256 channels)
+    E *T1 = (E *)(smem + LY::T1_OFF);    // [99][LDT]: conv1's output, row 98 zeros
+    E *T2 = (E *)(smem + LY::T2_OFF);    // [99][LDT]: the stem's (pooled) output, then conv2's output
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int img0 = blockIdx.x * RS_IMAGES;
     const int nimg = min(RS_IMAGES, a.n - img0), rows = nimg * RS_PIX;
     if (a.zero != nullptr)
         for (int i = blockIdx.x * 512 + tid; i < a.zero_quads; i += gridDim.x * 512) a.zero[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (tid < 16) *(f32x4 *)(T1 + RS_ZERO_ROW * RS_LDT + tid * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
-    rs_stem(a, smem, T2, img0, nimg, tid);
+    rs_stem<E>(a, smem, T2, img0, nimg, tid);
     __syncthreads();
+    // (the zero row lies where the stem's convolution images were)
+    if (tid < LDT * (int)sizeof(E) / 16) *(f32x4 *)((char *)(T1 + RS_ZERO_ROW * LDT) + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
     // first block: conv1 and the projection shortcut read the same input
-    rs_layer64<64, 1>(T2, RS_LDT, a.c1[0], T1, wave, lane);
-    rs_layer<7, 1, 2, 64, 1, false, false>(T2, RS_LDT, a.ds, 0, 2 * wave, X, RS_LDX, lane);
+    rs_layer64<E, 64, 1>(T2, LDT, a.c1[0], T1, wave, lane);
+    rs_layer<E, 7, 1, 2, 64, 1, false, false>(T2, LDT, a.ds, 0, 2 * wave, X, LDX, lane);
     __syncthreads();
-    rs_layer64<64, 9>(T1, RS_LDT, a.c2[0], T2, wave, lane);
+    rs_layer64<E, 64, 9>(T1, LDT, a.c2[0], T2, wave, lane);
     __syncthreads();
-    rs_layer<7, 1, 2, 64, 1, true, true>(T2, RS_LDT, a.c3[0], 0, 2 * wave, X, RS_LDX, lane);
+    rs_layer<E, 7, 1, 2, 64, 1, true, true>(T2, LDT, a.c3[0], 0, 2 * wave, X, LDX, lane);
     __syncthreads();
     for (int b = 1; b < a.nblocks; ++b) {
-        rs_layer64<256, 1>(X, RS_LDX, a.c1[b], T1, wave, lane);
+        rs_layer64<E, 256, 1>(X, LDX, a.c1[b], T1, wave, lane);
         __syncthreads();
-        rs_layer64<64, 9>(T1, RS_LDT, a.c2[b], T2, wave, lane);
+        rs_layer64<E, 64, 9>(T1, LDT, a.c2[b], T2, wave, lane);
         __syncthreads();
-        rs_layer<7, 1, 2, 64, 1, true, true>(T2, RS_LDT, a.c3[b], 0, 2 * wave, X, RS_LDX, lane);
+        rs_layer<E, 7, 1, 2, 64, 1, true, true>(T2, LDT, a.c3[b], 0, 2 * wave, X, LDX, lane);
         __syncthreads();
     }
     {
-        f32x4 *dst = (f32x4 *)(a.out + (size_t)img0 * RS_PIX * 256);
-        for (int i = tid; i < rows * 64; i += 512) {
-            const int r = i >> 6, c = (i & 63) * 4;
-            dst[i] = *(const f32x4 *)(X + r * RS_LDX + c);
+        constexpr int VEC = LY::VEC, QPR = 256 / VEC;  // 16-byte words per row
+        f32x4 *dst = (f32x4 *)((E *)a.out + (size_t)img0 * RS_PIX * 256);
+        for (int i = tid; i < rows * QPR; i += 512) {
+            const int r = i / QPR, c = (i - r * QPR) * VEC;
+            dst[i] = *(const f32x4 *)(X + r * LDX + c);
         }
     }
 }
@@ -297,6 +350,7 @@ static int g_rs_max_images = [] {
 }();
 
 struct ResidentStage {
+    int dtype;
     RsArgs args;            // layers filled in, in / out / n per launch
     double flops, executed, weight_bytes;  // per image (nominal, issued to the matrix cores) and once per launch
 };
@@ -305,34 +359,44 @@ bool resident_stage_enabled() { return g_rs_enabled; }
 int resident_stage_max_images() { return g_rs_max_images; }
 void resident_stage_free(ResidentStage *s) { delete s; }
 
-// Packs a torch [cout][cin][kh][kw] weight in the kernel's fragment order.
-static void rs_pack(const float *w, int cout, int cin, int taps, std::vector<float> &out) {
-    const int K = taps * cin, J = K / 16;
-    out.resize((size_t)cout * K);
+// Packs a torch [cout][cin][kh][kw] weight in the kernel's fragment order, rounded to `dtype` (nearest even).
+static void rs_pack(const float *w, int cout, int cin, int taps, int dtype, std::vector<uint8_t> &out) {
+    const int K = taps * cin, es = (int)dtype_size(dtype), vec = 16 / es, kg = dtype == DT_F32 ? 16 : 32, J = K / kg;
+    out.resize((size_t)cout * K * es);
     for (int cb = 0; cb < cout / 16; ++cb)
         for (int j = 0; j < J; ++j)
             for (int lane = 0; lane < 64; ++lane)
-                for (int s = 0; s < 4; ++s) {
-                    const int co = cb * 16 + (lane & 15), k = 16 * j + 4 * (lane >> 4) + s;
+                for (int s = 0; s < vec; ++s) {
+                    const int co = cb * 16 + (lane & 15), k = kg * j + vec * (lane >> 4) + s;
                     const int tap = k / cin, ci = k - tap * cin;
-                    out[(((size_t)cb * J + j) * 64 + lane) * 4 + s] = w[((size_t)co * cin + ci) * taps + tap];
+                    const float v = w[((size_t)co * cin + ci) * taps + tap];
+                    const size_t at = (((size_t)cb * J + j) * 64 + lane) * vec + s;
+                    if (dtype == DT_F32) {
+                        std::memcpy(&out[at * 4], &v, 4);
+                    } else {
+                        const uint16_t h = dtype == DT_BF16 ? f32_to_bf16_bits(v) : f32_to_f16_bits(v);
+                        std::memcpy(&out[at * 2], &h, 2);
+                    }
                 }
 }
 
 // weights: per block conv1, conv2, conv3 torch weights (w[3 b + i]) and the first block's shortcut;
 // layers: the blocks' ConvLayers (their device scale / shift arrays are shared).
-int resident_stage_new(DeviceArena &arena, int nblocks, const float *const *w, const float *w_ds, const ConvLayer *const *c1,
+int resident_stage_new(DeviceArena &arena, int dtype, int nblocks, const float *const *w, const float *w_ds, const ConvLayer *const *c1,
                        const ConvLayer *const *c2, const ConvLayer *const *c3, const ConvLayer *ds, const float *stem_w,
                        const float *stem_scale, const float *stem_shift, ResidentStage **out) {
     *out = nullptr;
     if (nblocks < 1 || nblocks > RS_MAX_BLOCKS) return GDPSO_OK;  // (not an error: the tiled kernels remain)
-    hipError_t e = hipFuncSetAttribute((const void *)stage_resident_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RS_LDS_BYTES);
+    hipError_t e = hipErrorUnknown;
+    GDPSO_WITH_DTYPE(dtype, e = hipFuncSetAttribute((const void *)stage_resident_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    (int)RsLds<E>::BYTES));
     if (e != hipSuccess) {
         (void)hipGetLastError();
         return GDPSO_OK;
     }
     auto s = new ResidentStage();
     std::memset(&s->args, 0, sizeof(s->args));
+    s->dtype = dtype;
     s->args.nblocks = nblocks;
     s->args.stem_w = stem_w;
     s->args.stem_scale = stem_scale;
@@ -341,17 +405,17 @@ int resident_stage_new(DeviceArena &arena, int nblocks, const float *const *w, c
     s->flops = 2.0 * ST_NPX * 64 * 49;
     s->executed = 2.0 * ST_NBLK * 16 * 64 * 4 * ST_KSTEPS;
     s->weight_bytes = 4.0 * 49 * 64;
-    std::vector<float> packed;
+    std::vector<uint8_t> packed;
     int rc = GDPSO_OK;
     auto add = [&](RsLayer &dst, const float *wt, const ConvLayer *L, int cin, int cout, int taps) {
         if (rc) return;
-        rs_pack(wt, cout, cin, taps, packed);
-        rc = arena.upload(packed, &dst.w);
+        rs_pack(wt, cout, cin, taps, dtype, packed);
+        rc = arena.upload(packed.data(), packed.size(), &dst.w);
         dst.scale = L->scale;
         dst.shift = L->shift;
         s->flops += L->flops_nominal;
         s->executed += 2.0 * 112 / 2 * cout * cin * taps;  // seven row blocks of 16 for two images
-        s->weight_bytes += 4.0 * cout * cin * taps;
+        s->weight_bytes += (double)dtype_size(dtype) * cout * cin * taps;
     };
     add(s->args.ds, w_ds, ds, 64, 256, 1);
     for (int b = 0; b < nblocks; ++b) {
@@ -367,7 +431,7 @@ int resident_stage_new(DeviceArena &arena, int nblocks, const float *const *w, c
     return GDPSO_OK;
 }
 
-int launch_resident_stage(const ResidentStage *s, hipStream_t stream, int n_images, const float *img01, float *out, void *zero,
+int launch_resident_stage(const ResidentStage *s, hipStream_t stream, int n_images, const float *img01, void *out, void *zero,
                           int zero_quads) {
     RsArgs a = s->args;
     a.img01 = img01;
@@ -378,11 +442,11 @@ int launch_resident_stage(const ResidentStage *s, hipStream_t stream, int n_imag
     const dim3 grid((unsigned)ceil_div(n_images, RS_IMAGES));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (conv_timing_slot(&e0, &e1)) {
-        hipExtLaunchKernelGGL(stage_resident_kernel, grid, dim3(512), RS_LDS_BYTES, stream, e0, e1, 0, a);
+        GDPSO_WITH_DTYPE(s->dtype, hipExtLaunchKernelGGL(stage_resident_kernel<E>, grid, dim3(512), RsLds<E>::BYTES, stream, e0, e1, 0, a));
         conv_timing_account(s->flops * n_images, s->executed * n_images,
-                            s->weight_bytes + 4.0 * n_images * (ST_SIDE * ST_SIDE + RS_PIX * 256));
+                            s->weight_bytes + (double)n_images * (4.0 * ST_SIDE * ST_SIDE + (double)dtype_size(s->dtype) * RS_PIX * 256));
     } else {
-        hipLaunchKernelGGL(stage_resident_kernel, grid, dim3(512), RS_LDS_BYTES, stream, a);
+        GDPSO_WITH_DTYPE(s->dtype, hipLaunchKernelGGL(stage_resident_kernel<E>, grid, dim3(512), RsLds<E>::BYTES, stream, a));
     }
     GDPSO_HIP(hipGetLastError());
     return GDPSO_OK;
