@@ -180,7 +180,7 @@ void conv_timing_account(double flops_nominal, double flops_executed, double byt
 
 // stage_resident.hip: the stem and the first ResNet stage in one launch with the activations resident in LDS
 // (28x28 images, 7x7 maps, 64 -> 64 -> 256 channel bottlenecks; any of the three element types).
-constexpr int RS_MAX_BLOCKS = 4;
+constexpr int RS_MAX_BLOCKS = 4, RS2_MAX_BLOCKS = 8;
 struct ResidentStage;
 struct DeviceArena;
 struct ConvLayer;
@@ -189,7 +189,11 @@ int resident_stage_max_images();
 // *out stays null (and GDPSO_OK is returned) when the device cannot run the kernel.
 int resident_stage_new(DeviceArena &arena, int dtype, int nblocks, const float *const *w, const float *w_ds, const ConvLayer *const *c1,
                        const ConvLayer *const *c2, const ConvLayer *const *c3, const ConvLayer *ds, const float *stem_w,
-                       const float *stem_scale, const float *stem_shift, ResidentStage **out);
+                       const float *stem_scale, const float *stem_shift, int nblocks2, const float *const *w2, const float *w2_ds,
+                       const ConvLayer *const *d1, const ConvLayer *const *d2, const ConvLayer *const *d3, const ConvLayer *ds2,
+                       ResidentStage **out);
+// Whether the handle's launch also runs the second stage (its output is then that stage's).
+bool resident_stage_has_second(const ResidentStage *s);
 void resident_stage_free(ResidentStage *s);
 // img01: the [n][28][28] images; out: the stage's NHWC output; zero / zero_quads: 16-byte words the launch clears on its way.
 int launch_resident_stage(const ResidentStage *s, hipStream_t stream, int n_images, const float *img01, void *out, void *zero,

@@ -914,6 +914,7 @@ struct gdpso_assessor {
     int chain_first = 0;  // first block behind the first stage
     // stem and first stage as one launch with the activations in LDS (stage_resident.hip), or null: 28x28 images only
     ResidentStage *resident = nullptr;
+    int resident_blocks = 0;  // blocks its launch covers: the first stage's, or the first two stages'
     ~gdpso_assessor() { resident_stage_free(resident); }
     const float *fc_w, *fc_b;
     int feat_c, feat_hw;
@@ -991,8 +992,9 @@ std::shared_ptr<const AssLayout> ass_layout(const gdpso_assessor *a, int n) {
     // launches not to matter, and two of its three layers per block already share one).  The chain reads
     // the first stage's output where it lies, keeps its intermediates in per-share slices of y-or-x / z /
     // t1 / t2 / sc and writes the last block's output to a buffer of its own.
-    L.chain_first = a->chain_first;
     L.resident = a->resident != nullptr && plan_batch(n) <= resident_stage_max_images();
+    // (a chain picks up behind the resident launch: behind the first stage, or behind the second)
+    L.chain_first = L.resident ? a->resident_blocks : a->chain_first;
     if (a->kind == 0 && chain_enabled() && L.chain_first > 0 && L.chain_first < (int)L.blocks.size()) {
         size_t zmax = 0;
         for (size_t i = L.chain_first; i < L.blocks.size(); ++i) zmax = std::max(zmax, out_elems(L.blocks[i].c3));
@@ -1090,8 +1092,8 @@ extern "C" int gdpso_assessor_create_resnet_typed(gdpso_assessor **out, const in
         a->flops = 2.0 * a->ho * a->ho * 64 * 49;
     }
     int cin = 64, h = a->hp;
-    std::vector<const float *> s1w;  // the first stage's torch weights: conv1, conv2, conv3 per block
-    const float *s1w_ds = nullptr;
+    std::vector<const float *> s1w, s2w;  // the first two stages' torch weights: conv1, conv2, conv3 per block
+    const float *s1w_ds = nullptr, *s2w_ds = nullptr;
     for (int s = 0; s < 4; ++s) {
         const int mid = 64 << s;
         for (int b = 0; b < depths[s]; ++b) {
@@ -1109,11 +1111,12 @@ extern "C" int gdpso_assessor_create_resnet_typed(gdpso_assessor **out, const in
             make_conv(blk.c3, t[ti + 10], mid * 4, mid, 1, 1, 1, 0, h2, h2, ACT_RELU, packed);  // ReLU after the residual add
             fold_bn(mid * 4, nullptr, t[ti + 11], t[ti + 12], t[ti + 13], t[ti + 14], sc, sh);
             if ((rc = upload_conv(a->arena, blk.c3, packed, sc, sh, dtype))) { delete a; return rc; }
-            if (s == 0) {
-                s1w.push_back(t[ti]);
-                s1w.push_back(t[ti + 5]);
-                s1w.push_back(t[ti + 10]);
-                if (b == 0) s1w_ds = t[ti + 15];
+            if (s <= 1) {
+                auto &sw = s == 0 ? s1w : s2w;
+                sw.push_back(t[ti]);
+                sw.push_back(t[ti + 5]);
+                sw.push_back(t[ti + 10]);
+                if (b == 0) (s == 0 ? s1w_ds : s2w_ds) = t[ti + 15];
             }
             ti += 15;
             blk.has_ds = (b == 0);
@@ -1134,14 +1137,16 @@ extern "C" int gdpso_assessor_create_resnet_typed(gdpso_assessor **out, const in
     a->feat_hw = h * h;
     a->chain_first = depths[0];
     if (img_side == 28 && depths[0] <= RS_MAX_BLOCKS && resident_stage_enabled()) {
-        std::vector<const ConvLayer *> c1, c2, c3;
-        for (int b = 0; b < depths[0]; ++b) {
-            c1.push_back(&a->blocks[b].c1);
-            c2.push_back(&a->blocks[b].c2);
-            c3.push_back(&a->blocks[b].c3);
+        std::vector<const ConvLayer *> c1, c2, c3, d1, d2, d3;
+        for (int b = 0; b < depths[0] + depths[1]; ++b) {
+            (b < depths[0] ? c1 : d1).push_back(&a->blocks[b].c1);
+            (b < depths[0] ? c2 : d2).push_back(&a->blocks[b].c2);
+            (b < depths[0] ? c3 : d3).push_back(&a->blocks[b].c3);
         }
         if ((rc = resident_stage_new(a->arena, dtype, depths[0], s1w.data(), s1w_ds, c1.data(), c2.data(), c3.data(), &a->blocks[0].ds,
-                                     a->stem_w, a->stem_scale, a->stem_shift, &a->resident))) { delete a; return rc; }
+                                     a->stem_w, a->stem_scale, a->stem_shift, depths[1], s2w.data(), s2w_ds, d1.data(), d2.data(),
+                                     d3.data(), &a->blocks[depths[0]].ds, &a->resident))) { delete a; return rc; }
+        a->resident_blocks = depths[0] + (resident_stage_has_second(a->resident) ? depths[1] : 0);
     }
     {
         std::vector<float> w(t[ti], t[ti] + (size_t)n_class * cin), b(t[ti + 1], t[ti + 1] + n_class);

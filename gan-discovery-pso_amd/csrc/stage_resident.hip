@@ -40,6 +40,7 @@ namespace gdpso {
 
 constexpr int RS_PIX = 49, RS_SIDE = 7, RS_IMAGES = 2, RS_ROWS = RS_PIX * RS_IMAGES;  // 98 rows = 7 blocks of 16
 constexpr int RS_ZERO_ROW = RS_ROWS;  // row 98 of the first intermediate: zeros (taps outside the image)
+constexpr int RS2_SIDE = 4, RS2_PIX = 16, RS2_ROWS = RS2_PIX * RS_IMAGES;  // second stage: 4x4 maps, 32 rows = 2 blocks of 16
 // The stem's scratch, floats whatever the element type: convolution images [2][208][68], padded images [2][34][36],
 // staged weights [49][80].
 constexpr int ST_SIDE = 28, ST_HO = 14, ST_NPX = ST_HO * ST_HO, ST_NBLK = (ST_NPX + 15) / 16, ST_PROWS = ST_SIDE + 6, ST_PS = 36;
@@ -61,7 +62,16 @@ struct RsLds {
     static constexpr size_t T1_OFF = X_BYTES;
     static constexpr size_t T2_OFF = X_BYTES + T_BYTES > ST_CONV_BYTES ? X_BYTES + T_BYTES : ST_CONV_BYTES;
     static constexpr size_t ST_IN_OFF = T_BYTES >= ST_IN_BYTES ? T2_OFF : T2_OFF + T_BYTES;
-    static constexpr size_t BYTES = ST_IN_OFF + ST_IN_BYTES > T2_OFF + T_BYTES ? ST_IN_OFF + ST_IN_BYTES : T2_OFF + T_BYTES;
+    static constexpr size_t BYTES1 = ST_IN_OFF + ST_IN_BYTES > T2_OFF + T_BYTES ? ST_IN_OFF + ST_IN_BYTES : T2_OFF + T_BYTES;
+    // Second stage (4x4 maps, 32 rows): U1 = conv1's output [99][128 + pad] behind X (98 rows of the 7x7 maps in the
+    // first block, 32 afterwards; row 98 zeros); once the first block's conv1 and shortcut have read X, the block
+    // output Y [32][512 + pad] and conv2's output U2 [32][128 + pad] lie where X was.
+    static constexpr int LDU = 128 + VEC, LDY = 512 + VEC;
+    static constexpr size_t U1_OFF = X_BYTES, U_BYTES = (size_t)(RS_ROWS + 1) * LDU * sizeof(E);
+    static constexpr size_t Y_BYTES = (size_t)RS2_ROWS * LDY * sizeof(E), U2_OFF = Y_BYTES, U2_BYTES = (size_t)RS2_ROWS * LDU * sizeof(E);
+    static constexpr size_t BYTES2 = U1_OFF + U_BYTES;
+    static_assert(U2_OFF + U2_BYTES <= X_BYTES && U2_OFF % 16 == 0, "second-stage buffers exceed the first stage's map");
+    static constexpr size_t BYTES = BYTES1 > BYTES2 ? BYTES1 : BYTES2;
     static_assert(ST_CONV_BYTES <= T2_OFF && ST_CONV_BYTES <= ST_IN_OFF, "the stem's convolution images overlap what is written while they are read");
     static_assert(T1_OFF % 16 == 0 && T2_OFF % 16 == 0 && ST_IN_OFF % 16 == 0 && BYTES <= 160 * 1024, "LDS layout");
 };
@@ -80,6 +90,9 @@ struct RsArgs {
     f32x4 *zero;         // 16-byte words this launch clears on its way (the control block of the chained launch behind it), or null
     int zero_quads;
     RsLayer ds, c1[RS_MAX_BLOCKS], c2[RS_MAX_BLOCKS], c3[RS_MAX_BLOCKS];
+    // second stage (kernel instantiations with S2): its shortcut and blocks; `out` is then [n][16][512]
+    int nblocks2;
+    RsLayer ds2, d1[RS2_MAX_BLOCKS], d2[RS2_MAX_BLOCKS], d3[RS2_MAX_BLOCKS];
 };
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
@@ -101,15 +114,19 @@ __device__ __forceinline__ f32x4 rs_mfma(const f32x4 &a, const f32x4 &b, f32x4 c
 using global_f32x4 = const __attribute__((address_space(1))) f32x4;
 using global_f32 = const __attribute__((address_space(1))) float;
 
-// One layer for one wave: NRB row blocks (rb0, rb0 + RBSTEP, ...) x NCB column blocks (cb0, cb0 + 1, ...),
-// CIN input channels per tap, TAPS = 1 (1x1) or 9 (3x3, padding 1).  A: LDS rows of lda elements; O: LDS rows of
-// ldo elements, also the residual when RES (each lane adds and overwrites its own elements).
-template <typename E, int NRB, int RBSTEP, int NCB, int CIN, int TAPS, bool RES, bool RELU>
-__device__ __forceinline__ void rs_layer(const E *__restrict__ A, const int lda, const RsLayer L, const int rb0, const int cb0,
-                                         E *O, const int ldo, const int lane) {
-    constexpr int VEC = RsLds<E>::VEC, KG = RsLds<E>::KG, GPT = CIN / KG, J = TAPS * GPT, PF = 3;
+// The matrix product of one layer for one wave: NRB row blocks (rb0, rb0 + RBSTEP, ...) x NCB column blocks
+// (cb0, cb0 + 1, ...) of 16 x 16 outputs, CIN input channels per tap, TAPS = 1 (1x1) or 9 (3x3, padding 1), input
+// maps of S_IN x S_IN pixels, output maps of S_OUT x S_OUT, stride STRIDE; two images a workgroup, rows in
+// (image, y, x) order.  A: LDS rows of lda elements, row RS_ZERO_ROW all zeros when TAPS = 9 (taps outside the map
+// read it).  ROWS_OUT: the output rows that exist (lanes of rows past them repeat the last one; their sums are
+// dropped by the epilogue).  PF: k groups of B fragments in flight ahead of the one being multiplied.
+template <typename E, int NRB, int RBSTEP, int NCB, int CIN, int TAPS, int S_IN, int S_OUT, int STRIDE, int ROWS_OUT, int PF>
+__device__ __forceinline__ void rs_gemm(const E *__restrict__ A, const int lda, const void *w, const int rb0, const int cb0,
+                                        const int lane, f32x4 (&acc)[NRB][NCB]) {
+    constexpr int VEC = RsLds<E>::VEC, KG = RsLds<E>::KG, GPT = CIN / KG, J = TAPS * GPT;
+    constexpr bool PLAIN = TAPS == 1 && STRIDE == 1;  // output row r reads input row r
     const int lrow = lane & 15, lk = lane >> 4;
-    global_f32x4 *bp = (global_f32x4 *)L.w + (size_t)cb0 * J * 64 + lane;
+    global_f32x4 *bp = (global_f32x4 *)w + (size_t)cb0 * J * 64 + lane;
     f32x4 bq[PF][NCB];
 #pragma unroll
     for (int p = 0; p < PF; ++p)
@@ -117,33 +134,34 @@ __device__ __forceinline__ void rs_layer(const E *__restrict__ A, const int lda,
 #pragma unroll
             for (int c = 0; c < NCB; ++c) bq[p][c] = bp[(c * J + p) * 64];
         }
-    float sc[NCB], sh[NCB];
-#pragma unroll
-    for (int c = 0; c < NCB; ++c) {
-        sc[c] = ((global_f32 *)L.scale)[(cb0 + c) * 16 + lrow];
-        sh[c] = ((global_f32 *)L.shift)[(cb0 + c) * 16 + lrow];
-    }
-    // this lane's A row per row block (rows past the two images repeat the last one; their results are dropped)
+    // this lane's A row per row block: the input row of the window's centre, and the centre's coordinates
     int arow[NRB], ay[NRB], ax[NRB];
 #pragma unroll
     for (int i = 0; i < NRB; ++i) {
-        const int row = min((rb0 + i * RBSTEP) * 16 + lrow, RS_ROWS - 1);
-        arow[i] = row;
-        const int p = row >= RS_PIX ? row - RS_PIX : row;
-        ay[i] = (p * 37) >> 8;  // p / 7 for p < 49
-        ax[i] = p - ay[i] * RS_SIDE;
+        const int row = ROWS_OUT % 16 == 0 ? (rb0 + i * RBSTEP) * 16 + lrow : min((rb0 + i * RBSTEP) * 16 + lrow, ROWS_OUT - 1);
+        if (PLAIN) {
+            arow[i] = row;
+            ay[i] = ax[i] = 0;
+        } else {
+            constexpr int PO = S_OUT * S_OUT;
+            const int im = row >= PO ? 1 : 0, p = row - im * PO;
+            const int oy = S_OUT == 4 ? p >> 2 : (p * 37) >> 8;  // p / S_OUT (p / 7 for p < 49)
+            const int ox = p - oy * S_OUT;
+            ay[i] = oy * STRIDE;
+            ax[i] = ox * STRIDE;
+            arow[i] = im * S_IN * S_IN + ay[i] * S_IN + ax[i];
+        }
     }
     auto a_load = [&](int i, int j) -> f32x4 {
         const int tap = j / GPT, c0 = (j - tap * GPT) * KG;
         int row = arow[i];
         if (TAPS == 9) {
             const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-            const bool ok = (unsigned)(ay[i] + dy) < (unsigned)RS_SIDE && (unsigned)(ax[i] + dx) < (unsigned)RS_SIDE;
-            row = ok ? row + dy * RS_SIDE + dx : RS_ZERO_ROW;
+            const bool ok = (unsigned)(ay[i] + dy) < (unsigned)S_IN && (unsigned)(ax[i] + dx) < (unsigned)S_IN;
+            row = ok ? row + dy * S_IN + dx : RS_ZERO_ROW;
         }
         return *(const f32x4 *)(A + row * lda + c0 + VEC * lk);
     };
-    f32x4 acc[NRB][NCB];
 #pragma unroll
     for (int i = 0; i < NRB; ++i)
 #pragma unroll
@@ -182,18 +200,38 @@ __device__ __forceinline__ void rs_layer(const E *__restrict__ A, const int lda,
                 for (int c = 0; c < NCB; ++c) acc[i][c] = rs_mfma<E>(aq[j & 1][i], bcur[c], acc[i][c]);
         }
     }
-    // epilogue: BatchNorm scale / shift, residual, ReLU; lane holds rows 4 lk + r of column lrow of each block
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// BatchNorm scale / shift of a wave's column blocks (lane: column l & 15); requested ahead of the product.
+template <int NCB>
+__device__ __forceinline__ void rs_affine(const RsLayer &L, int cb0, int lane, float (&sc)[NCB], float (&sh)[NCB]) {
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) {
+        sc[c] = ((global_f32 *)L.scale)[(cb0 + c) * 16 + (lane & 15)];
+        sh[c] = ((global_f32 *)L.shift)[(cb0 + c) * 16 + (lane & 15)];
+    }
+}
+
+// Epilogue: scale / shift, residual, ReLU, rounded to E on the way to LDS (O: rows of ldo elements).  A lane holds
+// rows 4 (l >> 4) + r of column l & 15 of each block.  RES: 0 none, 1 the elements of O it overwrites, 2 `keep`
+// (what rs_keep left in registers, same blocks).
+template <typename E, int NRB, int RBSTEP, int NCB, int ROWS_OUT, int RES, bool RELU>
+__device__ __forceinline__ void rs_store(const f32x4 (&acc)[NRB][NCB], const float (&sc)[NCB], const float (&sh)[NCB], E *O, const int ldo,
+                                         const int rb0, const int cb0, const int lane, const f32x4 (&keep)[NRB][NCB]) {
+    const int lrow = lane & 15, lk = lane >> 4;
 #pragma unroll
     for (int i = 0; i < NRB; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = (rb0 + i * RBSTEP) * 16 + 4 * lk + r;
-            if (row < RS_ROWS) {
+            if (ROWS_OUT % 16 == 0 || row < ROWS_OUT) {
 #pragma unroll
                 for (int c = 0; c < NCB; ++c) {
                     E *o = O + row * ldo + (cb0 + c) * 16 + lrow;
                     float v = acc[i][c][r] * sc[c] + sh[c];
-                    if (RES) v += (float)*o;
+                    if (RES == 1) v += (float)*o;
+                    if (RES == 2) v += keep[i][c][r];
                     if (RELU) v = fmaxf(v, 0.f);
                     *o = (E)v;
                 }
@@ -201,7 +239,31 @@ __device__ __forceinline__ void rs_layer(const E *__restrict__ A, const int lda,
         }
 }
 
-// A layer of 64 output channels over the whole workgroup (8 waves).
+// A layer's result kept in registers for a later layer's residual (the projection shortcut of the second stage, whose
+// blocks are those of the 1x1 layer that adds it): scale / shift, rounded to E as a stored result would be.
+template <typename E, int NRB, int NCB>
+__device__ __forceinline__ void rs_keep(const f32x4 (&acc)[NRB][NCB], const float (&sc)[NCB], const float (&sh)[NCB], f32x4 (&keep)[NRB][NCB]) {
+#pragma unroll
+    for (int i = 0; i < NRB; ++i)
+#pragma unroll
+        for (int c = 0; c < NCB; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) keep[i][c][r] = (float)(E)(acc[i][c][r] * sc[c] + sh[c]);
+}
+
+// One layer of the first stage for one wave (7x7 maps, 98 rows): product + epilogue.
+template <typename E, int NRB, int RBSTEP, int NCB, int CIN, int TAPS, bool RES, bool RELU>
+__device__ __forceinline__ void rs_layer(const E *__restrict__ A, const int lda, const RsLayer L, const int rb0, const int cb0,
+                                         E *O, const int ldo, const int lane) {
+    float sc[NCB], sh[NCB];
+    rs_affine<NCB>(L, cb0, lane, sc, sh);
+    f32x4 acc[NRB][NCB];
+    rs_gemm<E, NRB, RBSTEP, NCB, CIN, TAPS, RS_SIDE, RS_SIDE, 1, RS_ROWS, 3>(A, lda, L.w, rb0, cb0, lane, acc);
+    rs_store<E, NRB, RBSTEP, NCB, RS_ROWS, RES ? 1 : 0, RELU>(acc, sc, sh, O, ldo, rb0, cb0, lane, acc);
+}
+
+// A layer of 64 output channels over the whole workgroup (8 waves): wave w takes column block w & 3 and the even
+// (w < 4) or odd row blocks.
 template <typename E, int CIN, int TAPS>
 __device__ __forceinline__ void rs_layer64(const E *A, int lda, const RsLayer L, E *O, int wave, int lane) {
     if (wave < 4)
@@ -293,7 +355,69 @@ __device__ __forceinline__ void rs_stem(const RsArgs &a, char *smem, E *T2, int 
     }
 }
 
+// The second stage for the workgroup's two images, from the first stage's output in X (reference
+// src/pso/util_cnn.py:95, 147-157: bottlenecks of 128 -> 128 -> 512 channels, the first with stride 2 in its 3x3
+// convolution and a strided 1x1 projection shortcut; 7x7 -> 4x4 maps).  32 rows = two row blocks: a wave takes one
+// column block of a 128-column layer (k groups six ahead: its groups are short) or four of a 512-column layer, both
+// row blocks each.  The shortcut's blocks are those its wave owns in conv3, so its result waits in registers.
 template <typename E>
+__device__ __forceinline__ void rs_stage2(const RsArgs &a, char *smem, int wave, int lane, int tid) {
+    using LY = RsLds<E>;
+    constexpr int LDX = LY::LDX, LDU = LY::LDU, LDY = LY::LDY;
+    E *X = (E *)smem, *U1 = (E *)(smem + LY::U1_OFF), *Y = (E *)smem, *U2 = (E *)(smem + LY::U2_OFF);
+    if (tid < LDU * (int)sizeof(E) / 16) *(f32x4 *)((char *)(U1 + RS_ZERO_ROW * LDU) + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 keep[2][4];
+    {
+        float sc[1], sh[1];
+        rs_affine<1>(a.d1[0], wave, lane, sc, sh);
+        f32x4 acc[7][1];
+        rs_gemm<E, 7, 1, 1, 256, 1, RS_SIDE, RS_SIDE, 1, RS_ROWS, 3>(X, LDX, a.d1[0].w, 0, wave, lane, acc);
+        rs_store<E, 7, 1, 1, RS_ROWS, 0, true>(acc, sc, sh, U1, LDU, 0, wave, lane, acc);
+    }
+    {
+        float sc[4], sh[4];
+        rs_affine<4>(a.ds2, 4 * wave, lane, sc, sh);
+        f32x4 acc[2][4];
+        rs_gemm<E, 2, 1, 4, 256, 1, RS_SIDE, RS2_SIDE, 2, RS2_ROWS, 3>(X, LDX, a.ds2.w, 0, 4 * wave, lane, acc);
+        rs_keep<E, 2, 4>(acc, sc, sh, keep);
+    }
+    __syncthreads();
+    for (int b = 0; b < a.nblocks2; ++b) {
+        if (b > 0) {
+            float sc[1], sh[1];
+            rs_affine<1>(a.d1[b], wave, lane, sc, sh);
+            f32x4 acc[2][1];
+            rs_gemm<E, 2, 1, 1, 512, 1, RS2_SIDE, RS2_SIDE, 1, RS2_ROWS, 6>(Y, LDY, a.d1[b].w, 0, wave, lane, acc);
+            rs_store<E, 2, 1, 1, RS2_ROWS, 0, true>(acc, sc, sh, U1, LDU, 0, wave, lane, acc);
+            __syncthreads();
+        }
+        {
+            float sc[1], sh[1];
+            rs_affine<1>(a.d2[b], wave, lane, sc, sh);
+            f32x4 acc[2][1];
+            if (b == 0)
+                rs_gemm<E, 2, 1, 1, 128, 9, RS_SIDE, RS2_SIDE, 2, RS2_ROWS, 6>(U1, LDU, a.d2[b].w, 0, wave, lane, acc);
+            else
+                rs_gemm<E, 2, 1, 1, 128, 9, RS2_SIDE, RS2_SIDE, 1, RS2_ROWS, 6>(U1, LDU, a.d2[b].w, 0, wave, lane, acc);
+            rs_store<E, 2, 1, 1, RS2_ROWS, 0, true>(acc, sc, sh, U2, LDU, 0, wave, lane, acc);
+        }
+        __syncthreads();
+        {
+            float sc[4], sh[4];
+            rs_affine<4>(a.d3[b], 4 * wave, lane, sc, sh);
+            f32x4 acc[2][4];
+            rs_gemm<E, 2, 1, 4, 128, 1, RS2_SIDE, RS2_SIDE, 1, RS2_ROWS, 3>(U2, LDU, a.d3[b].w, 0, 4 * wave, lane, acc);
+            if (b == 0)
+                rs_store<E, 2, 1, 4, RS2_ROWS, 2, true>(acc, sc, sh, Y, LDY, 0, 4 * wave, lane, keep);
+            else
+                rs_store<E, 2, 1, 4, RS2_ROWS, 1, true>(acc, sc, sh, Y, LDY, 0, 4 * wave, lane, keep);
+        }
+        __syncthreads();
+    }
+}
+
+// S2: the second stage behind the first, `out` = its output [n][16][512]; else `out` = the first stage's [n][49][256].
+template <typename E, bool S2>
 __global__ __launch_bounds__(512) void stage_resident_kernel(const RsArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using LY = RsLds<E>;
@@ -303,7 +427,7 @@ __global__ __launch_bounds__(512) void stage_resident_kernel(const RsArgs a) {
     E *T2 = (E *)(smem + LY::T2_OFF);    // [99][LDT]: the stem's (pooled) output, then conv2's output
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int img0 = blockIdx.x * RS_IMAGES;
-    const int nimg = min(RS_IMAGES, a.n - img0), rows = nimg * RS_PIX;
+    const int nimg = min(RS_IMAGES, a.n - img0);
     if (a.zero != nullptr)
         for (int i = blockIdx.x * 512 + tid; i < a.zero_quads; i += gridDim.x * 512) a.zero[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     rs_stem<E>(a, smem, T2, img0, nimg, tid);
@@ -326,10 +450,19 @@ __global__ __launch_bounds__(512) void stage_resident_kernel(const RsArgs a) {
         rs_layer<E, 7, 1, 2, 64, 1, true, true>(T2, LDT, a.c3[b], 0, 2 * wave, X, LDX, lane);
         __syncthreads();
     }
-    {
-        constexpr int VEC = LY::VEC, QPR = 256 / VEC;  // 16-byte words per row
+    constexpr int VEC = LY::VEC;
+    if constexpr (S2) {
+        rs_stage2<E>(a, smem, wave, lane, tid);
+        constexpr int QPR = 512 / VEC;  // 16-byte words per row
+        f32x4 *dst = (f32x4 *)((E *)a.out + (size_t)img0 * RS2_PIX * 512);
+        for (int i = tid; i < nimg * RS2_PIX * QPR; i += 512) {
+            const int r = i / QPR, c = (i - r * QPR) * VEC;
+            dst[i] = *(const f32x4 *)((E *)smem + r * LY::LDY + c);
+        }
+    } else {
+        constexpr int QPR = 256 / VEC;
         f32x4 *dst = (f32x4 *)((E *)a.out + (size_t)img0 * RS_PIX * 256);
-        for (int i = tid; i < rows * QPR; i += 512) {
+        for (int i = tid; i < nimg * RS_PIX * QPR; i += 512) {
             const int r = i / QPR, c = (i - r * QPR) * VEC;
             dst[i] = *(const f32x4 *)(X + r * LDX + c);
         }
@@ -351,11 +484,19 @@ static int g_rs_max_images = [] {
 
 struct ResidentStage {
     int dtype;
+    bool stage2;            // the second stage rides along (args.nblocks2 blocks)
     RsArgs args;            // layers filled in, in / out / n per launch
     double flops, executed, weight_bytes;  // per image (nominal, issued to the matrix cores) and once per launch
 };
 
+// The second stage in the same launch (0: the resident launch ends with the first stage).
+static bool g_rs_stage2 = [] {
+    const char *e = getenv("GDPSO_STAGE2_RESIDENT");
+    return e ? e[0] != '0' : true;
+}();
+
 bool resident_stage_enabled() { return g_rs_enabled; }
+bool resident_stage_has_second(const ResidentStage *s) { return s != nullptr && s->stage2; }
 int resident_stage_max_images() { return g_rs_max_images; }
 void resident_stage_free(ResidentStage *s) { delete s; }
 
@@ -384,12 +525,18 @@ static void rs_pack(const float *w, int cout, int cin, int taps, int dtype, std:
 // layers: the blocks' ConvLayers (their device scale / shift arrays are shared).
 int resident_stage_new(DeviceArena &arena, int dtype, int nblocks, const float *const *w, const float *w_ds, const ConvLayer *const *c1,
                        const ConvLayer *const *c2, const ConvLayer *const *c3, const ConvLayer *ds, const float *stem_w,
-                       const float *stem_scale, const float *stem_shift, ResidentStage **out) {
+                       const float *stem_scale, const float *stem_shift, int nblocks2, const float *const *w2, const float *w2_ds,
+                       const ConvLayer *const *d1, const ConvLayer *const *d2, const ConvLayer *const *d3, const ConvLayer *ds2,
+                       ResidentStage **out) {
     *out = nullptr;
     if (nblocks < 1 || nblocks > RS_MAX_BLOCKS) return GDPSO_OK;  // (not an error: the tiled kernels remain)
+    if (nblocks2 > RS2_MAX_BLOCKS || !g_rs_stage2) nblocks2 = 0;
     hipError_t e = hipErrorUnknown;
-    GDPSO_WITH_DTYPE(dtype, e = hipFuncSetAttribute((const void *)stage_resident_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    GDPSO_WITH_DTYPE(dtype, e = hipFuncSetAttribute((const void *)stage_resident_kernel<E, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                     (int)RsLds<E>::BYTES));
+    if (e == hipSuccess)
+        GDPSO_WITH_DTYPE(dtype, e = hipFuncSetAttribute((const void *)stage_resident_kernel<E, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        (int)RsLds<E>::BYTES));
     if (e != hipSuccess) {
         (void)hipGetLastError();
         return GDPSO_OK;
@@ -407,14 +554,14 @@ int resident_stage_new(DeviceArena &arena, int dtype, int nblocks, const float *
     s->weight_bytes = 4.0 * 49 * 64;
     std::vector<uint8_t> packed;
     int rc = GDPSO_OK;
-    auto add = [&](RsLayer &dst, const float *wt, const ConvLayer *L, int cin, int cout, int taps) {
+    auto add = [&](RsLayer &dst, const float *wt, const ConvLayer *L, int cin, int cout, int taps, int rows = 112) {
         if (rc) return;
         rs_pack(wt, cout, cin, taps, dtype, packed);
         rc = arena.upload(packed.data(), packed.size(), &dst.w);
         dst.scale = L->scale;
         dst.shift = L->shift;
         s->flops += L->flops_nominal;
-        s->executed += 2.0 * 112 / 2 * cout * cin * taps;  // seven row blocks of 16 for two images
+        s->executed += 2.0 * rows / 2 * cout * cin * taps;  // row blocks of 16 for two images: seven on the 7x7 maps, two on the 4x4
         s->weight_bytes += (double)dtype_size(dtype) * cout * cin * taps;
     };
     add(s->args.ds, w_ds, ds, 64, 256, 1);
@@ -422,6 +569,16 @@ int resident_stage_new(DeviceArena &arena, int dtype, int nblocks, const float *
         add(s->args.c1[b], w[3 * b], c1[b], b == 0 ? 64 : 256, 64, 1);
         add(s->args.c2[b], w[3 * b + 1], c2[b], 64, 64, 9);
         add(s->args.c3[b], w[3 * b + 2], c3[b], 64, 256, 1);
+    }
+    s->stage2 = nblocks2 > 0;
+    s->args.nblocks2 = nblocks2;
+    if (s->stage2) {
+        add(s->args.ds2, w2_ds, ds2, 256, 512, 1, 32);
+        for (int b = 0; b < nblocks2; ++b) {
+            add(s->args.d1[b], w2[3 * b], d1[b], b == 0 ? 256 : 512, 128, 1, b == 0 ? 112 : 32);
+            add(s->args.d2[b], w2[3 * b + 1], d2[b], 128, 128, 9, 32);
+            add(s->args.d3[b], w2[3 * b + 2], d3[b], 128, 512, 1, 32);
+        }
     }
     if (rc) {
         delete s;
@@ -441,23 +598,33 @@ int launch_resident_stage(const ResidentStage *s, hipStream_t stream, int n_imag
     a.zero_quads = zero_quads;
     const dim3 grid((unsigned)ceil_div(n_images, RS_IMAGES));
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (conv_timing_slot(&e0, &e1)) {
-        GDPSO_WITH_DTYPE(s->dtype, hipExtLaunchKernelGGL(stage_resident_kernel<E>, grid, dim3(512), RsLds<E>::BYTES, stream, e0, e1, 0, a));
-        conv_timing_account(s->flops * n_images, s->executed * n_images,
-                            s->weight_bytes + (double)n_images * (4.0 * ST_SIDE * ST_SIDE + (double)dtype_size(s->dtype) * RS_PIX * 256));
-    } else {
-        GDPSO_WITH_DTYPE(s->dtype, hipLaunchKernelGGL(stage_resident_kernel<E>, grid, dim3(512), RsLds<E>::BYTES, stream, a));
+    const double out_elems = s->stage2 ? (double)RS2_PIX * 512 : (double)RS_PIX * 256;
+#define GDPSO_RS_LAUNCH(S2)                                                                                                       \
+    if (conv_timing_slot(&e0, &e1)) {                                                                                             \
+        GDPSO_WITH_DTYPE(s->dtype, hipExtLaunchKernelGGL((stage_resident_kernel<E, S2>), grid, dim3(512), RsLds<E>::BYTES, stream, e0, e1, 0, a)); \
+        conv_timing_account(s->flops * n_images, s->executed * n_images,                                                         \
+                            s->weight_bytes + (double)n_images * (4.0 * ST_SIDE * ST_SIDE + (double)dtype_size(s->dtype) * out_elems)); \
+    } else {                                                                                                                      \
+        GDPSO_WITH_DTYPE(s->dtype, hipLaunchKernelGGL((stage_resident_kernel<E, S2>), grid, dim3(512), RsLds<E>::BYTES, stream, a));   \
     }
+    if (s->stage2) {
+        GDPSO_RS_LAUNCH(true)
+    } else {
+        GDPSO_RS_LAUNCH(false)
+    }
+#undef GDPSO_RS_LAUNCH
     GDPSO_HIP(hipGetLastError());
     return GDPSO_OK;
 }
 
 }  // namespace gdpso
 
-extern "C" int gdpso_resident_options(int enabled, int max_images) {
+extern "C" int gdpso_resident_options(int stages, int max_images) {
     using namespace gdpso;
+    GDPSO_REQUIRE(stages >= 0 && stages <= 2, "resident_options: stages must be 0, 1 or 2");
     GDPSO_REQUIRE(max_images >= 0, "resident_options: max_images must be 0 (keep) or a batch size");
-    g_rs_enabled = enabled != 0;
+    g_rs_enabled = stages != 0;
+    g_rs_stage2 = stages == 2;
     if (max_images > 0) g_rs_max_images = max_images;
     return GDPSO_OK;
 }

@@ -145,12 +145,13 @@ def plan_options(plan_images: int = 0, splitk: bool = True) -> None:
     check(_lib.lib().gdpso_plan_options(int(plan_images), int(bool(splitk))))
 
 
-def resident_options(enabled: bool = True, max_images: int = 0) -> None:
-    """Switches of the resident first ResNet stage (gdpso_resident_options; pack the assessor AFTER the
-    call).  ``enabled`` False: the first stage runs through the tiled convolution kernels.  ``max_images``
-    > 0: largest planned batch that takes the resident kernel (0: keep the current limit).  The two paths
-    agree to fp32 rounding, not bit for bit."""
-    check(_lib.lib().gdpso_resident_options(int(bool(enabled)), int(max_images)))
+def resident_options(stages: int = 2, max_images: int = 0) -> None:
+    """Switches of the resident stages (gdpso_resident_options; pack the assessor AFTER the call).
+    ``stages`` 0: stem and every ResNet stage through the tiled convolution kernels; 1: stem and first stage
+    in one launch with their maps in LDS; 2 (default): the second stage too.  ``max_images`` > 0: largest
+    planned batch that takes the resident kernel (0: keep the current limit).  The paths agree to fp32
+    rounding, not bit for bit."""
+    check(_lib.lib().gdpso_resident_options(int(stages), int(max_images)))
 
 
 class _Handle:

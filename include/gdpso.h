@@ -407,15 +407,17 @@ int gdpso_chain_debug(int enabled, unsigned drop_xcc_mask, int teams);
  * GDPSO_PLAN_SPLITK give the initial values. */
 int gdpso_plan_options(int plan_images, int splitk);
 
-/* No counterpart in the reference: switches of the resident first stage (the bottleneck blocks of the first
- * ResNet stage, reference src/pso/util_cnn.py:94, 147-157, in ONE launch whose workgroups keep two images'
- * maps in LDS; fp32 assessors on 28x28 images only).  Applies to assessors created and launch plans made from
- * now on.  enabled = 0: the first stage runs through the tiled convolution kernels like the other element
- * types (A/B runs and tests).  max_images > 0: the largest (planned, see gdpso_plan_options) batch that takes
- * the resident kernel; 0 keeps the current limit (default 1024: larger batches fill the device better with
- * the tiled kernels).  The two paths add a row's products in different orders and agree to fp32 rounding.
- * Environment: GDPSO_STAGE1_RESIDENT, GDPSO_STAGE1_RESIDENT_MAX give the initial values. */
-int gdpso_resident_options(int enabled, int max_images);
+/* No counterpart in the reference: switches of the resident stages (the stem and the bottleneck blocks of the
+ * first two ResNet stages, reference src/pso/util_cnn.py:85-95, 103-110, 147-157, in ONE launch whose workgroups
+ * keep two images' maps in LDS; assessors on 28x28 images only, any element type).  Applies to assessors
+ * created and launch plans made from now on.  stages = 0: stem and every stage run through the tiled kernels
+ * (A/B runs and tests); 1: the stem and the first stage are resident; 2 (default): the second stage as well.
+ * max_images > 0: the largest (planned, see gdpso_plan_options) batch that takes the resident kernel; 0 keeps
+ * the current limit (default 1024: larger batches fill the device better with the tiled kernels).  The paths
+ * add a row's products in different orders and agree to fp32 rounding (to the element type's rounding for 16-bit
+ * storage).  Environment: GDPSO_STAGE1_RESIDENT (0: none), GDPSO_STAGE2_RESIDENT (0: first stage only),
+ * GDPSO_STAGE1_RESIDENT_MAX give the initial values. */
+int gdpso_resident_options(int stages, int max_images);
 
 /* No counterpart in the reference: the tile shape (64, 32 or 16, as in gdpso_conv_probe) a convolution layer
  * would run with as a step of a chained launch over n_images images with `teams` (1 or 2) teams per XCD, or 0

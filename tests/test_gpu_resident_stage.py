@@ -1,7 +1,7 @@
-"""The resident first stage (the first ResNet stage in one launch, two images' maps in a workgroup's LDS)
-against the tiled convolution kernels of the same assessor and against the oracle.  The two paths add a
-row's products in different orders: the comparison between them is to fp32 rounding; an image's result
-must not depend on the batch it arrives in nor on its place in the batch."""
+"""The resident stages (the stem and the first, or the first two, ResNet stages in one launch, two images'
+maps in a workgroup's LDS) against the tiled convolution kernels of the same assessor and against the
+oracle.  The paths add a row's products in different orders: the comparison between them is to fp32
+rounding; an image's result must not depend on the batch it arrives in nor on its place in the batch."""
 import importlib
 
 import numpy as np
@@ -18,7 +18,7 @@ def eng():
 
 def _logits(eng, synth, model, x, resident, max_images=1024, n_class=8, dtype="f32"):
     dev = torch.device("cuda:0")
-    eng.resident_options(resident, max_images)
+    eng.resident_options(int(resident), max_images)
     try:
         ass = eng.PackedAssessor(synth.resnet_state(model, 1, n_class, seed=12), dev, img_side=28, dtype=dtype)
         gen = eng.PackedGenerator(synth.generator_state(10, 1, 64, seed=11), dev, dtype=dtype)
@@ -28,7 +28,7 @@ def _logits(eng, synth, model, x, resident, max_images=1024, n_class=8, dtype="f
             _, logits = ev.assess(x, eng.FitnessSpec(class_index=0), want_logits=True)
             out.append(logits.cpu().numpy().copy())
     finally:
-        eng.resident_options(True, 1024)
+        eng.resident_options(2, 1024)
     np.testing.assert_array_equal(out[1], out[0])
     return out[0]
 
@@ -41,11 +41,14 @@ def _images(n, seed=5):
                                      ("ResNet50", 1024), ("ResNet101", 128), ("ResNet152", 64)])
 def test_resident_stage_matches_tiled_kernels(eng, synth, model, n):
     x = _images(n)
-    tiled = _logits(eng, synth, model, x, resident=False)
-    resident = _logits(eng, synth, model, x, resident=True)
-    assert np.isfinite(resident).all()
-    np.testing.assert_allclose(resident, tiled, rtol=1e-4, atol=2e-4)
-    assert not np.array_equal(resident, tiled) or n < 8  # (the other path did run: the sums are ordered differently)
+    tiled = _logits(eng, synth, model, x, resident=0)
+    first = _logits(eng, synth, model, x, resident=1)
+    both = _logits(eng, synth, model, x, resident=2)
+    for resident in (first, both):
+        assert np.isfinite(resident).all()
+        np.testing.assert_allclose(resident, tiled, rtol=1e-4, atol=2e-4)
+        assert not np.array_equal(resident, tiled) or n < 8  # (the other path did run: the sums are ordered differently)
+    assert not np.array_equal(first, both) or n < 8
 
 
 @pytest.mark.parametrize("dtype,bar", [("bf16", 0.6), ("f16", 0.08)])
@@ -55,8 +58,10 @@ def test_resident_stage_16bit(eng, synth, oracle, dtype, bar, n):
     orders, so they differ where a rounding falls the other way; each is held to the bar of the 16-bit
     configurations against the fp32 oracle (logits |d|, tests/test_gpu_lowprec.py), and to that bar against the other."""
     x = _images(n, seed=7)
-    tiled = _logits(eng, synth, "ResNet50", x, resident=False, dtype=dtype)
-    resident = _logits(eng, synth, "ResNet50", x, resident=True, dtype=dtype)
+    tiled = _logits(eng, synth, "ResNet50", x, resident=0, dtype=dtype)
+    first = _logits(eng, synth, "ResNet50", x, resident=1, dtype=dtype)
+    np.testing.assert_allclose(first, tiled, atol=bar)
+    resident = _logits(eng, synth, "ResNet50", x, resident=2, dtype=dtype)
     assert np.isfinite(resident).all()
     np.testing.assert_allclose(resident, tiled, atol=bar)
     csd = synth.to_torch(synth.resnet_state("ResNet50", 1, 8, seed=12))
@@ -71,7 +76,7 @@ def test_resident_stage_16bit(eng, synth, oracle, dtype, bar, n):
 def test_resident_stage_against_oracle(eng, synth, oracle):
     n = 100
     x = _images(n, seed=9)
-    got = _logits(eng, synth, "ResNet50", x, resident=True)
+    got = _logits(eng, synth, "ResNet50", x, resident=2)
     csd = synth.to_torch(synth.resnet_state("ResNet50", 1, 8, seed=12))
     sel = np.concatenate([[0, 1, 2, n - 2, n - 1], np.random.RandomState(1).choice(n, 11, replace=False)])
     with torch.no_grad():
@@ -85,8 +90,8 @@ def test_an_image_gets_the_same_bits_in_any_batch(eng, synth):
     eng.plan_options(plan_images=64, splitk=False)
     try:
         x = _images(129)
-        whole = _logits(eng, synth, "ResNet50", x, resident=True)
-        odd = _logits(eng, synth, "ResNet50", x[1:66].contiguous(), resident=True)  # image k of this batch is image k + 1 of the other
+        whole = _logits(eng, synth, "ResNet50", x, resident=2)
+        odd = _logits(eng, synth, "ResNet50", x[1:66].contiguous(), resident=2)  # image k of this batch is image k + 1 of the other
     finally:
         eng.plan_options(plan_images=0, splitk=True)
     np.testing.assert_array_equal(odd, whole[1:66])
@@ -94,6 +99,6 @@ def test_an_image_gets_the_same_bits_in_any_batch(eng, synth):
 
 def test_limit_sends_large_batches_to_the_tiled_kernels(eng, synth):
     x = _images(64)
-    tiled = _logits(eng, synth, "ResNet50", x, resident=False)
-    limited = _logits(eng, synth, "ResNet50", x, resident=True, max_images=32)
+    tiled = _logits(eng, synth, "ResNet50", x, resident=0)
+    limited = _logits(eng, synth, "ResNet50", x, resident=2, max_images=32)
     np.testing.assert_array_equal(limited, tiled)
