@@ -104,7 +104,8 @@ _PROTOTYPES = {
     "gdpso_chain_debug": (c_int, [c_int, C.c_uint, c_int]),
     "gdpso_chain_stats": (c_int, [C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
     "gdpso_plan_options": (c_int, [c_int, c_int]),
-    "gdpso_resident_options": (c_int, [c_int, c_int]),
+    "gdpso_resident_options": (c_int, [c_int, c_int, c_int]),
+    "gdpso_resident_force_images": (c_int, [c_int]),
     "gdpso_chain_tile_describe": (c_int, [c_int] * 10),
     "gdpso_conv_probe": (c_int, [c_int] * 11 + [C.POINTER(c_double), C.POINTER(c_int), C.POINTER(c_int)]),
     "gdpso_conv_probe_typed": (c_int, [c_int] * 11 + [C.POINTER(c_double), C.POINTER(c_int), C.POINTER(c_int), c_int]),

@@ -185,7 +185,8 @@ struct ResidentStage;
 struct DeviceArena;
 struct ConvLayer;
 bool resident_stage_enabled();
-int resident_stage_max_images();
+// Images a workgroup of the resident launch takes for a batch planned as n_images (1 or 2), or 0: the tiled kernels.
+int resident_stage_images(int n_images, int num_cus);
 // *out stays null (and GDPSO_OK is returned) when the device cannot run the kernel.
 int resident_stage_new(DeviceArena &arena, int dtype, int nblocks, const float *const *w, const float *w_ds, const ConvLayer *const *c1,
                        const ConvLayer *const *c2, const ConvLayer *const *c3, const ConvLayer *ds, const float *stem_w,
@@ -196,8 +197,11 @@ int resident_stage_new(DeviceArena &arena, int dtype, int nblocks, const float *
 bool resident_stage_has_second(const ResidentStage *s);
 void resident_stage_free(ResidentStage *s);
 // img01: the [n][28][28] images; out: the stage's NHWC output; zero / zero_quads: 16-byte words the launch clears on its way.
-int launch_resident_stage(const ResidentStage *s, hipStream_t stream, int n_images, const float *img01, void *out, void *zero,
-                          int zero_quads);
+// second: go on through the second stage (out: that stage's output); only with resident_stage_has_second.
+int launch_resident_stage(const ResidentStage *s, hipStream_t stream, int n_images, int images_per_wg, bool second, const float *img01,
+                          void *out, void *zero, int zero_quads);
+// Whether a batch planned as n_images should take the second stage along.
+bool resident_stage_second(const ResidentStage *s, int n_images);
 
 // host-side helpers (pack.cpp)
 struct DeviceArena {

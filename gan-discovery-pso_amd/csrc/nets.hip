@@ -932,6 +932,8 @@ struct AssLayout {
     ConvChain *chain = nullptr;
     int chain_first = 0;
     bool resident = false;  // blocks [0, chain_first) through the handle's resident stage at this batch size
+    int resident_images = 0;  // ... with this many images a workgroup
+    bool resident_second = false;  // ... and the second stage in the same launch
     AssLayout() = default;
     AssLayout(const AssLayout &) = delete;
     AssLayout &operator=(const AssLayout &) = delete;
@@ -992,9 +994,11 @@ std::shared_ptr<const AssLayout> ass_layout(const gdpso_assessor *a, int n) {
     // launches not to matter, and two of its three layers per block already share one).  The chain reads
     // the first stage's output where it lies, keeps its intermediates in per-share slices of y-or-x / z /
     // t1 / t2 / sc and writes the last block's output to a buffer of its own.
-    L.resident = a->resident != nullptr && plan_batch(n) <= resident_stage_max_images();
+    L.resident_images = a->resident != nullptr ? resident_stage_images(plan_batch(n), a->num_cus) : 0;
+    L.resident = L.resident_images > 0;
     // (a chain picks up behind the resident launch: behind the first stage, or behind the second)
-    L.chain_first = L.resident ? a->resident_blocks : a->chain_first;
+    L.resident_second = L.resident && resident_stage_second(a->resident, plan_batch(n));
+    L.chain_first = L.resident ? (L.resident_second ? a->resident_blocks : a->chain_first) : a->chain_first;
     if (a->kind == 0 && chain_enabled() && L.chain_first > 0 && L.chain_first < (int)L.blocks.size()) {
         size_t zmax = 0;
         for (size_t i = L.chain_first; i < L.blocks.size(); ++i) zmax = std::max(zmax, out_elems(L.blocks[i].c3));
@@ -1311,7 +1315,7 @@ static int assessor_forward_impl(const gdpso_assessor *a, void *stream_, int n, 
         // stem and first stage in one launch; its output lies where the tiled kernels would have left it (in x
         // after an even number of blocks, else in y)
         if (L.chain_first % 2 == 1) std::swap(x, y);
-        if ((rc = launch_resident_stage(a->resident, stream, n, img01, x, ctl_zero, ctl_quads))) return rc;
+        if ((rc = launch_resident_stage(a->resident, stream, n, L.resident_images, L.resident_second, img01, x, ctl_zero, ctl_quads))) return rc;
     } else if (stem_mfma && mfma_smem <= 64 * 1024) {
         GDPSO_WITH_DTYPE(a->dtype, hipLaunchKernelGGL(stem_mfma_kernel<E>, dim3(n), dim3(512), mfma_smem, stream, img01, a->stem_w,
                                                       a->stem_scale, a->stem_shift, a->side, a->ho, a->hp, mps,

@@ -251,25 +251,36 @@ __device__ __forceinline__ void rs_keep(const f32x4 (&acc)[NRB][NCB], const floa
             for (int r = 0; r < 4; ++r) keep[i][c][r] = (float)(E)(acc[i][c][r] * sc[c] + sh[c]);
 }
 
-// One layer of the first stage for one wave (7x7 maps, 98 rows): product + epilogue.
-template <typename E, int NRB, int RBSTEP, int NCB, int CIN, int TAPS, bool RES, bool RELU>
+// One layer of the first stage for one wave (7x7 maps, 49 rows an image): product + epilogue.
+template <typename E, int IMG, int NRB, int RBSTEP, int NCB, int CIN, int TAPS, bool RES, bool RELU>
 __device__ __forceinline__ void rs_layer(const E *__restrict__ A, const int lda, const RsLayer L, const int rb0, const int cb0,
                                          E *O, const int ldo, const int lane) {
     float sc[NCB], sh[NCB];
     rs_affine<NCB>(L, cb0, lane, sc, sh);
     f32x4 acc[NRB][NCB];
-    rs_gemm<E, NRB, RBSTEP, NCB, CIN, TAPS, RS_SIDE, RS_SIDE, 1, RS_ROWS, 3>(A, lda, L.w, rb0, cb0, lane, acc);
-    rs_store<E, NRB, RBSTEP, NCB, RS_ROWS, RES ? 1 : 0, RELU>(acc, sc, sh, O, ldo, rb0, cb0, lane, acc);
+    rs_gemm<E, NRB, RBSTEP, NCB, CIN, TAPS, RS_SIDE, RS_SIDE, 1, IMG * RS_PIX, 3>(A, lda, L.w, rb0, cb0, lane, acc);
+    rs_store<E, NRB, RBSTEP, NCB, IMG * RS_PIX, RES ? 1 : 0, RELU>(acc, sc, sh, O, ldo, rb0, cb0, lane, acc);
 }
 
-// A layer of 64 output channels over the whole workgroup (8 waves): wave w takes column block w & 3 and the even
-// (w < 4) or odd row blocks.
-template <typename E, int CIN, int TAPS>
+// A layer of 64 output channels over the whole workgroup (8 waves): wave w takes column block w & 3 and half of the
+// row blocks: of the seven of two images the even (w < 4: four) or odd ones (three), of the four of one image the
+// first or the last two.
+template <typename E, int IMG, int CIN, int TAPS>
 __device__ __forceinline__ void rs_layer64(const E *A, int lda, const RsLayer L, E *O, int wave, int lane) {
-    if (wave < 4)
-        rs_layer<E, 4, 2, 1, CIN, TAPS, false, true>(A, lda, L, 0, wave & 3, O, RsLds<E>::LDT, lane);
-    else
-        rs_layer<E, 3, 2, 1, CIN, TAPS, false, true>(A, lda, L, 1, wave & 3, O, RsLds<E>::LDT, lane);
+    if constexpr (IMG == 2) {
+        if (wave < 4)
+            rs_layer<E, IMG, 4, 2, 1, CIN, TAPS, false, true>(A, lda, L, 0, wave & 3, O, RsLds<E>::LDT, lane);
+        else
+            rs_layer<E, IMG, 3, 2, 1, CIN, TAPS, false, true>(A, lda, L, 1, wave & 3, O, RsLds<E>::LDT, lane);
+    } else {
+        rs_layer<E, IMG, 2, 1, 1, CIN, TAPS, false, true>(A, lda, L, 2 * (wave >> 2), wave & 3, O, RsLds<E>::LDT, lane);
+    }
+}
+
+// A 1x1 layer of 64 -> 256 channels: wave w takes column blocks 2w, 2w + 1 and every row block.
+template <typename E, int IMG, bool RES, bool RELU>
+__device__ __forceinline__ void rs_layer256(const E *A, const RsLayer L, E *X, int wave, int lane) {
+    rs_layer<E, IMG, (IMG * RS_PIX + 15) / 16, 1, 2, 64, 1, RES, RELU>(A, RsLds<E>::LDT, L, 0, 2 * wave, X, RsLds<E>::LDX, lane);
 }
 
 // The stem for the workgroup's two images: Conv2d(1 -> 64, k7, s2, p3, no bias) + BatchNorm + ReLU + MaxPool2d(3, s2, p1)
@@ -279,13 +290,13 @@ __device__ __forceinline__ void rs_layer64(const E *A, int lda, const RsLayer L,
 // l & 15] at step t, K padded to 52 with zero weights.  The convolution images (2 x 208 rows x 68 floats) lie where
 // the 256-channel map and the first intermediate will be; padded images and staged weights where the pooled result
 // goes once they are dead (see RsLds).
-template <typename E>
+template <typename E, int IMG>
 __device__ __forceinline__ void rs_stem(const RsArgs &a, char *smem, E *T2, int img0, int nimg, int tid) {
     const int lane = tid & 63, wave = tid >> 6, lrow = lane & 15, lk = lane >> 4;
     float *s_conv = (float *)smem;                            // [2][208][68]
     float *s_img = (float *)(smem + RsLds<E>::ST_IN_OFF);     // [2][34][36], zero border of 3
     float *s_w = s_img + RS_IMAGES * ST_IMG_FLOATS;           // [49][80]
-    for (int i = tid; i < RS_IMAGES * ST_IMG_FLOATS; i += 512) {
+    for (int i = tid; i < IMG * ST_IMG_FLOATS; i += 512) {
         const int im = i / ST_IMG_FLOATS, q = i - im * ST_IMG_FLOATS, row = q / ST_PS, col = q - row * ST_PS;
         const int y = row - 3, x = col - 3;
         float v = 0.f;
@@ -314,7 +325,7 @@ __device__ __forceinline__ void rs_stem(const RsArgs &a, char *smem, E *T2, int 
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) bw[t][cb] = k < 49 ? s_w[k * ST_LDW + cb * 16 + lrow] : 0.f;
     }
-    for (int b = wave; b < RS_IMAGES * ST_NBLK; b += 8) {
+    for (int b = wave; b < IMG * ST_NBLK; b += 8) {
         const int im = b >= ST_NBLK ? 1 : 0, bb = b - im * ST_NBLK;
         const int px = min(bb * 16 + lrow, ST_NPX - 1);  // rows past the image repeat the last pixel; they are never read back
         const int y = px / ST_HO, x = px - y * ST_HO;
@@ -337,7 +348,7 @@ __device__ __forceinline__ void rs_stem(const RsArgs &a, char *smem, E *T2, int 
     }
     __syncthreads();
     // MaxPool2d(3, s2, p1) into the rows of the first block's input; consecutive threads take consecutive channels
-    for (int e = tid; e < RS_ROWS * 64; e += 512) {
+    for (int e = tid; e < IMG * RS_PIX * 64; e += 512) {
         const int c = e & 63, pp = e >> 6, im = pp >= RS_PIX ? 1 : 0, p = pp - im * RS_PIX, pr = (p * 37) >> 8, pc = p - pr * RS_SIDE;
         float m = -INFINITY;
 #pragma unroll
@@ -360,64 +371,67 @@ __device__ __forceinline__ void rs_stem(const RsArgs &a, char *smem, E *T2, int 
 // convolution and a strided 1x1 projection shortcut; 7x7 -> 4x4 maps).  32 rows = two row blocks: a wave takes one
 // column block of a 128-column layer (k groups six ahead: its groups are short) or four of a 512-column layer, both
 // row blocks each.  The shortcut's blocks are those its wave owns in conv3, so its result waits in registers.
-template <typename E>
+template <typename E, int IMG>
 __device__ __forceinline__ void rs_stage2(const RsArgs &a, char *smem, int wave, int lane, int tid) {
     using LY = RsLds<E>;
     constexpr int LDX = LY::LDX, LDU = LY::LDU, LDY = LY::LDY;
+    constexpr int ROWS1 = IMG * RS_PIX, NRB1 = (ROWS1 + 15) / 16, ROWS2 = IMG * RS2_PIX, NRB2 = ROWS2 / 16;
     E *X = (E *)smem, *U1 = (E *)(smem + LY::U1_OFF), *Y = (E *)smem, *U2 = (E *)(smem + LY::U2_OFF);
     if (tid < LDU * (int)sizeof(E) / 16) *(f32x4 *)((char *)(U1 + RS_ZERO_ROW * LDU) + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 keep[2][4];
+    f32x4 keep[NRB2][4];
     {
         float sc[1], sh[1];
         rs_affine<1>(a.d1[0], wave, lane, sc, sh);
-        f32x4 acc[7][1];
-        rs_gemm<E, 7, 1, 1, 256, 1, RS_SIDE, RS_SIDE, 1, RS_ROWS, 3>(X, LDX, a.d1[0].w, 0, wave, lane, acc);
-        rs_store<E, 7, 1, 1, RS_ROWS, 0, true>(acc, sc, sh, U1, LDU, 0, wave, lane, acc);
+        f32x4 acc[NRB1][1];
+        rs_gemm<E, NRB1, 1, 1, 256, 1, RS_SIDE, RS_SIDE, 1, ROWS1, 3>(X, LDX, a.d1[0].w, 0, wave, lane, acc);
+        rs_store<E, NRB1, 1, 1, ROWS1, 0, true>(acc, sc, sh, U1, LDU, 0, wave, lane, acc);
     }
     {
         float sc[4], sh[4];
         rs_affine<4>(a.ds2, 4 * wave, lane, sc, sh);
-        f32x4 acc[2][4];
-        rs_gemm<E, 2, 1, 4, 256, 1, RS_SIDE, RS2_SIDE, 2, RS2_ROWS, 3>(X, LDX, a.ds2.w, 0, 4 * wave, lane, acc);
-        rs_keep<E, 2, 4>(acc, sc, sh, keep);
+        f32x4 acc[NRB2][4];
+        rs_gemm<E, NRB2, 1, 4, 256, 1, RS_SIDE, RS2_SIDE, 2, ROWS2, 3>(X, LDX, a.ds2.w, 0, 4 * wave, lane, acc);
+        rs_keep<E, NRB2, 4>(acc, sc, sh, keep);
     }
     __syncthreads();
     for (int b = 0; b < a.nblocks2; ++b) {
         if (b > 0) {
             float sc[1], sh[1];
             rs_affine<1>(a.d1[b], wave, lane, sc, sh);
-            f32x4 acc[2][1];
-            rs_gemm<E, 2, 1, 1, 512, 1, RS2_SIDE, RS2_SIDE, 1, RS2_ROWS, 6>(Y, LDY, a.d1[b].w, 0, wave, lane, acc);
-            rs_store<E, 2, 1, 1, RS2_ROWS, 0, true>(acc, sc, sh, U1, LDU, 0, wave, lane, acc);
+            f32x4 acc[NRB2][1];
+            rs_gemm<E, NRB2, 1, 1, 512, 1, RS2_SIDE, RS2_SIDE, 1, ROWS2, 6>(Y, LDY, a.d1[b].w, 0, wave, lane, acc);
+            rs_store<E, NRB2, 1, 1, ROWS2, 0, true>(acc, sc, sh, U1, LDU, 0, wave, lane, acc);
             __syncthreads();
         }
         {
             float sc[1], sh[1];
             rs_affine<1>(a.d2[b], wave, lane, sc, sh);
-            f32x4 acc[2][1];
+            f32x4 acc[NRB2][1];
             if (b == 0)
-                rs_gemm<E, 2, 1, 1, 128, 9, RS_SIDE, RS2_SIDE, 2, RS2_ROWS, 6>(U1, LDU, a.d2[b].w, 0, wave, lane, acc);
+                rs_gemm<E, NRB2, 1, 1, 128, 9, RS_SIDE, RS2_SIDE, 2, ROWS2, 6>(U1, LDU, a.d2[b].w, 0, wave, lane, acc);
             else
-                rs_gemm<E, 2, 1, 1, 128, 9, RS2_SIDE, RS2_SIDE, 1, RS2_ROWS, 6>(U1, LDU, a.d2[b].w, 0, wave, lane, acc);
-            rs_store<E, 2, 1, 1, RS2_ROWS, 0, true>(acc, sc, sh, U2, LDU, 0, wave, lane, acc);
+                rs_gemm<E, NRB2, 1, 1, 128, 9, RS2_SIDE, RS2_SIDE, 1, ROWS2, 6>(U1, LDU, a.d2[b].w, 0, wave, lane, acc);
+            rs_store<E, NRB2, 1, 1, ROWS2, 0, true>(acc, sc, sh, U2, LDU, 0, wave, lane, acc);
         }
         __syncthreads();
         {
             float sc[4], sh[4];
             rs_affine<4>(a.d3[b], 4 * wave, lane, sc, sh);
-            f32x4 acc[2][4];
-            rs_gemm<E, 2, 1, 4, 128, 1, RS2_SIDE, RS2_SIDE, 1, RS2_ROWS, 3>(U2, LDU, a.d3[b].w, 0, 4 * wave, lane, acc);
+            f32x4 acc[NRB2][4];
+            rs_gemm<E, NRB2, 1, 4, 128, 1, RS2_SIDE, RS2_SIDE, 1, ROWS2, 3>(U2, LDU, a.d3[b].w, 0, 4 * wave, lane, acc);
             if (b == 0)
-                rs_store<E, 2, 1, 4, RS2_ROWS, 2, true>(acc, sc, sh, Y, LDY, 0, 4 * wave, lane, keep);
+                rs_store<E, NRB2, 1, 4, ROWS2, 2, true>(acc, sc, sh, Y, LDY, 0, 4 * wave, lane, keep);
             else
-                rs_store<E, 2, 1, 4, RS2_ROWS, 1, true>(acc, sc, sh, Y, LDY, 0, 4 * wave, lane, keep);
+                rs_store<E, NRB2, 1, 4, ROWS2, 1, true>(acc, sc, sh, Y, LDY, 0, 4 * wave, lane, keep);
         }
         __syncthreads();
     }
 }
 
 // S2: the second stage behind the first, `out` = its output [n][16][512]; else `out` = the first stage's [n][49][256].
-template <typename E, bool S2>
+// IMG: images a workgroup takes, 2 or 1 (batches that leave half the CUs without a workgroup otherwise: a
+// workgroup's time goes with its row blocks, 7 -> 4 on the 7x7 maps, 2 -> 1 on the 4x4; same LDS layout, same bits).
+template <typename E, bool S2, int IMG>
 __global__ __launch_bounds__(512) void stage_resident_kernel(const RsArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using LY = RsLds<E>;
@@ -426,33 +440,33 @@ __global__ __launch_bounds__(512) void stage_resident_kernel(const RsArgs a) {
     E *T1 = (E *)(smem + LY::T1_OFF);    // [99][LDT]: conv1's output, row 98 zeros
     E *T2 = (E *)(smem + LY::T2_OFF);    // [99][LDT]: the stem's (pooled) output, then conv2's output
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int img0 = blockIdx.x * RS_IMAGES;
-    const int nimg = min(RS_IMAGES, a.n - img0);
+    const int img0 = blockIdx.x * IMG;
+    const int nimg = min(IMG, a.n - img0);
     if (a.zero != nullptr)
         for (int i = blockIdx.x * 512 + tid; i < a.zero_quads; i += gridDim.x * 512) a.zero[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    rs_stem<E>(a, smem, T2, img0, nimg, tid);
+    rs_stem<E, IMG>(a, smem, T2, img0, nimg, tid);
     __syncthreads();
     // (the zero row lies where the stem's convolution images were)
     if (tid < LDT * (int)sizeof(E) / 16) *(f32x4 *)((char *)(T1 + RS_ZERO_ROW * LDT) + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
     // first block: conv1 and the projection shortcut read the same input
-    rs_layer64<E, 64, 1>(T2, LDT, a.c1[0], T1, wave, lane);
-    rs_layer<E, 7, 1, 2, 64, 1, false, false>(T2, LDT, a.ds, 0, 2 * wave, X, LDX, lane);
+    rs_layer64<E, IMG, 64, 1>(T2, LDT, a.c1[0], T1, wave, lane);
+    rs_layer256<E, IMG, false, false>(T2, a.ds, X, wave, lane);
     __syncthreads();
-    rs_layer64<E, 64, 9>(T1, LDT, a.c2[0], T2, wave, lane);
+    rs_layer64<E, IMG, 64, 9>(T1, LDT, a.c2[0], T2, wave, lane);
     __syncthreads();
-    rs_layer<E, 7, 1, 2, 64, 1, true, true>(T2, LDT, a.c3[0], 0, 2 * wave, X, LDX, lane);
+    rs_layer256<E, IMG, true, true>(T2, a.c3[0], X, wave, lane);
     __syncthreads();
     for (int b = 1; b < a.nblocks; ++b) {
-        rs_layer64<E, 256, 1>(X, LDX, a.c1[b], T1, wave, lane);
+        rs_layer64<E, IMG, 256, 1>(X, LDX, a.c1[b], T1, wave, lane);
         __syncthreads();
-        rs_layer64<E, 64, 9>(T1, LDT, a.c2[b], T2, wave, lane);
+        rs_layer64<E, IMG, 64, 9>(T1, LDT, a.c2[b], T2, wave, lane);
         __syncthreads();
-        rs_layer<E, 7, 1, 2, 64, 1, true, true>(T2, LDT, a.c3[b], 0, 2 * wave, X, LDX, lane);
+        rs_layer256<E, IMG, true, true>(T2, a.c3[b], X, wave, lane);
         __syncthreads();
     }
     constexpr int VEC = LY::VEC;
     if constexpr (S2) {
-        rs_stage2<E>(a, smem, wave, lane, tid);
+        rs_stage2<E, IMG>(a, smem, wave, lane, tid);
         constexpr int QPR = 512 / VEC;  // 16-byte words per row
         f32x4 *dst = (f32x4 *)((E *)a.out + (size_t)img0 * RS2_PIX * 512);
         for (int i = tid; i < nimg * RS2_PIX * QPR; i += 512) {
@@ -481,12 +495,23 @@ static int g_rs_max_images = [] {
     const char *e = getenv("GDPSO_STAGE1_RESIDENT_MAX");
     return e ? atoi(e) : 1024;
 }();
+// Smallest batch that takes it: below, a handful of workgroups walk some sixty layers on a few CUs while the tiled
+// kernels spread every layer over the device.
+static int g_rs_min_images = [] {
+    const char *e = getenv("GDPSO_STAGE1_RESIDENT_MIN");
+    return e ? atoi(e) : 64;
+}();
 
 struct ResidentStage {
     int dtype;
     bool stage2;            // the second stage rides along (args.nblocks2 blocks)
     RsArgs args;            // layers filled in, in / out / n per launch
-    double flops, executed, weight_bytes;  // per image (nominal, issued to the matrix cores) and once per launch
+    // per image: nominal FLOPs, FLOPs issued to the matrix cores with two images (executed) or one (executed1) a
+    // workgroup (row blocks of 16: 7 for 98 rows, 4 for 49); weight bytes once per launch; of the stem and the first
+    // stage, and of both stages
+    struct Work {
+        double flops, executed, executed1, weight_bytes;
+    } first, both;
 };
 
 // The second stage in the same launch (0: the resident launch ends with the first stage).
@@ -495,9 +520,14 @@ static bool g_rs_stage2 = [] {
     return e ? e[0] != '0' : true;
 }();
 
+static int g_rs2_min_images = [] {
+    const char *e = getenv("GDPSO_STAGE2_RESIDENT_MIN");
+    return e ? atoi(e) : 160;
+}();
+static int g_rs_force_images = 0;  // test aid (gdpso_resident_force_images)
+
 bool resident_stage_enabled() { return g_rs_enabled; }
 bool resident_stage_has_second(const ResidentStage *s) { return s != nullptr && s->stage2; }
-int resident_stage_max_images() { return g_rs_max_images; }
 void resident_stage_free(ResidentStage *s) { delete s; }
 
 // Packs a torch [cout][cin][kh][kw] weight in the kernel's fragment order, rounded to `dtype` (nearest even).
@@ -531,12 +561,13 @@ int resident_stage_new(DeviceArena &arena, int dtype, int nblocks, const float *
     *out = nullptr;
     if (nblocks < 1 || nblocks > RS_MAX_BLOCKS) return GDPSO_OK;  // (not an error: the tiled kernels remain)
     if (nblocks2 > RS2_MAX_BLOCKS || !g_rs_stage2) nblocks2 = 0;
-    hipError_t e = hipErrorUnknown;
-    GDPSO_WITH_DTYPE(dtype, e = hipFuncSetAttribute((const void *)stage_resident_kernel<E, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                    (int)RsLds<E>::BYTES));
-    if (e == hipSuccess)
-        GDPSO_WITH_DTYPE(dtype, e = hipFuncSetAttribute((const void *)stage_resident_kernel<E, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                        (int)RsLds<E>::BYTES));
+    hipError_t e = hipSuccess;
+#define GDPSO_RS_ATTR(S2, IMG)                                                                                                         \
+    if (e == hipSuccess)                                                                                                               \
+        GDPSO_WITH_DTYPE(dtype, e = hipFuncSetAttribute((const void *)stage_resident_kernel<E, S2, IMG>,                                \
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)RsLds<E>::BYTES));
+    GDPSO_RS_ATTR(false, 1) GDPSO_RS_ATTR(false, 2) GDPSO_RS_ATTR(true, 1) GDPSO_RS_ATTR(true, 2)
+#undef GDPSO_RS_ATTR
     if (e != hipSuccess) {
         (void)hipGetLastError();
         return GDPSO_OK;
@@ -549,20 +580,22 @@ int resident_stage_new(DeviceArena &arena, int dtype, int nblocks, const float *
     s->args.stem_scale = stem_scale;
     s->args.stem_shift = stem_shift;
     // the stem: 196 pixels x 64 channels x 49 taps per image (13 row blocks of 16, K padded to 52, on the matrix cores)
-    s->flops = 2.0 * ST_NPX * 64 * 49;
-    s->executed = 2.0 * ST_NBLK * 16 * 64 * 4 * ST_KSTEPS;
-    s->weight_bytes = 4.0 * 49 * 64;
+    ResidentStage::Work wk;
+    wk.flops = 2.0 * ST_NPX * 64 * 49;
+    wk.executed = wk.executed1 = 2.0 * ST_NBLK * 16 * 64 * 4 * ST_KSTEPS;
+    wk.weight_bytes = 4.0 * 49 * 64;
     std::vector<uint8_t> packed;
     int rc = GDPSO_OK;
-    auto add = [&](RsLayer &dst, const float *wt, const ConvLayer *L, int cin, int cout, int taps, int rows = 112) {
+    auto add = [&](RsLayer &dst, const float *wt, const ConvLayer *L, int cin, int cout, int taps, int rows = 112, int rows1 = 64) {
         if (rc) return;
         rs_pack(wt, cout, cin, taps, dtype, packed);
         rc = arena.upload(packed.data(), packed.size(), &dst.w);
         dst.scale = L->scale;
         dst.shift = L->shift;
-        s->flops += L->flops_nominal;
-        s->executed += 2.0 * rows / 2 * cout * cin * taps;  // row blocks of 16 for two images: seven on the 7x7 maps, two on the 4x4
-        s->weight_bytes += (double)dtype_size(dtype) * cout * cin * taps;
+        wk.flops += L->flops_nominal;
+        wk.executed += 2.0 * rows / 2 * cout * cin * taps;  // row blocks of 16 for two images: seven on the 7x7 maps, two on the 4x4
+        wk.executed1 += 2.0 * rows1 * cout * cin * taps;   // ... for one image: four and one
+        wk.weight_bytes += (double)dtype_size(dtype) * cout * cin * taps;
     };
     add(s->args.ds, w_ds, ds, 64, 256, 1);
     for (int b = 0; b < nblocks; ++b) {
@@ -570,16 +603,18 @@ int resident_stage_new(DeviceArena &arena, int dtype, int nblocks, const float *
         add(s->args.c2[b], w[3 * b + 1], c2[b], 64, 64, 9);
         add(s->args.c3[b], w[3 * b + 2], c3[b], 64, 256, 1);
     }
+    s->first = wk;
     s->stage2 = nblocks2 > 0;
     s->args.nblocks2 = nblocks2;
     if (s->stage2) {
-        add(s->args.ds2, w2_ds, ds2, 256, 512, 1, 32);
+        add(s->args.ds2, w2_ds, ds2, 256, 512, 1, 32, 16);
         for (int b = 0; b < nblocks2; ++b) {
-            add(s->args.d1[b], w2[3 * b], d1[b], b == 0 ? 256 : 512, 128, 1, b == 0 ? 112 : 32);
-            add(s->args.d2[b], w2[3 * b + 1], d2[b], 128, 128, 9, 32);
-            add(s->args.d3[b], w2[3 * b + 2], d3[b], 128, 512, 1, 32);
+            add(s->args.d1[b], w2[3 * b], d1[b], b == 0 ? 256 : 512, 128, 1, b == 0 ? 112 : 32, b == 0 ? 64 : 16);
+            add(s->args.d2[b], w2[3 * b + 1], d2[b], 128, 128, 9, 32, 16);
+            add(s->args.d3[b], w2[3 * b + 2], d3[b], 128, 512, 1, 32, 16);
         }
     }
+    s->both = wk;
     if (rc) {
         delete s;
         return rc;
@@ -588,29 +623,64 @@ int resident_stage_new(DeviceArena &arena, int dtype, int nblocks, const float *
     return GDPSO_OK;
 }
 
-int launch_resident_stage(const ResidentStage *s, hipStream_t stream, int n_images, const float *img01, void *out, void *zero,
-                          int zero_quads) {
+// How many images a workgroup of the resident launch should take for a batch planned as n_images on a device of
+// num_cus CUs: 0 (the tiled kernels serve the batch better), 1 or 2.  A workgroup holds its CU for the whole run of
+// layers, so the launch takes rounds x (time of one workgroup): one image a workgroup while that still leaves every
+// image a CU of its own, two up to two images per CU; beyond, whole rounds of 2 x num_cus images, worth it only
+// when the last round is nearly full (measured on MI355X, 256 CUs, fp32: 64 ... 256 images one a workgroup, ... 512
+// two; 768 images = 1.5 rounds lose to the tiled kernels, 1024 = 2 rounds win).
+int resident_stage_images(int n_images, int num_cus) {
+    if (n_images < g_rs_min_images || n_images > g_rs_max_images) return 0;
+    if (g_rs_force_images > 0) return g_rs_force_images;
+    if (n_images <= num_cus) return 1;
+    if (n_images <= 2 * num_cus) return 2;
+    const long capacity = (long)ceil_div(ceil_div(n_images, 2), num_cus) * 2 * num_cus;
+    return (long)n_images * 100 >= capacity * 85 ? 2 : 0;
+}
+
+// Whether the launch should go on through the second stage for a batch planned as n_images: with few workgroups
+// its long layers on a handful of CUs lose to the chained launch, which spreads them over the device (measured:
+// even at 128 images, +6 % at 192, +5 % at 256).
+bool resident_stage_second(const ResidentStage *s, int n_images) { return s != nullptr && s->stage2 && n_images >= g_rs2_min_images; }
+
+int launch_resident_stage(const ResidentStage *s, hipStream_t stream, int n_images, int images_per_wg, bool second, const float *img01,
+                          void *out, void *zero, int zero_quads) {
+    if (images_per_wg != 1 && images_per_wg != 2) return fail(GDPSO_ERR_ARG, "resident stage: one or two images a workgroup");
+    if (second && !s->stage2) return fail(GDPSO_ERR_ARG, "resident stage: the handle holds no second stage");
     RsArgs a = s->args;
     a.img01 = img01;
     a.out = out;
     a.n = n_images;
     a.zero = (f32x4 *)zero;
     a.zero_quads = zero_quads;
-    const dim3 grid((unsigned)ceil_div(n_images, RS_IMAGES));
+    const dim3 grid((unsigned)ceil_div(n_images, images_per_wg));
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    const double out_elems = s->stage2 ? (double)RS2_PIX * 512 : (double)RS_PIX * 256;
-#define GDPSO_RS_LAUNCH(S2)                                                                                                       \
-    if (conv_timing_slot(&e0, &e1)) {                                                                                             \
-        GDPSO_WITH_DTYPE(s->dtype, hipExtLaunchKernelGGL((stage_resident_kernel<E, S2>), grid, dim3(512), RsLds<E>::BYTES, stream, e0, e1, 0, a)); \
-        conv_timing_account(s->flops * n_images, s->executed * n_images,                                                         \
-                            s->weight_bytes + (double)n_images * (4.0 * ST_SIDE * ST_SIDE + (double)dtype_size(s->dtype) * out_elems)); \
-    } else {                                                                                                                      \
-        GDPSO_WITH_DTYPE(s->dtype, hipLaunchKernelGGL((stage_resident_kernel<E, S2>), grid, dim3(512), RsLds<E>::BYTES, stream, a));   \
+    const double out_elems = second ? (double)RS2_PIX * 512 : (double)RS_PIX * 256;
+    const bool timed = conv_timing_slot(&e0, &e1);
+    if (timed) {
+        const ResidentStage::Work &w = second ? s->both : s->first;
+        conv_timing_account(w.flops * n_images, (images_per_wg == 2 ? w.executed : w.executed1) * n_images,
+                            w.weight_bytes + (double)n_images * (4.0 * ST_SIDE * ST_SIDE + (double)dtype_size(s->dtype) * out_elems));
     }
-    if (s->stage2) {
-        GDPSO_RS_LAUNCH(true)
+#define GDPSO_RS_LAUNCH(S2, IMG)                                                                                                            \
+    if (timed) {                                                                                                                            \
+        GDPSO_WITH_DTYPE(s->dtype, hipExtLaunchKernelGGL((stage_resident_kernel<E, S2, IMG>), grid, dim3(512), RsLds<E>::BYTES, stream, e0, \
+                                                         e1, 0, a));                                                                        \
+    } else {                                                                                                                                \
+        GDPSO_WITH_DTYPE(s->dtype, hipLaunchKernelGGL((stage_resident_kernel<E, S2, IMG>), grid, dim3(512), RsLds<E>::BYTES, stream, a));    \
+    }
+    if (second) {
+        if (images_per_wg == 2) {
+            GDPSO_RS_LAUNCH(true, 2)
+        } else {
+            GDPSO_RS_LAUNCH(true, 1)
+        }
     } else {
-        GDPSO_RS_LAUNCH(false)
+        if (images_per_wg == 2) {
+            GDPSO_RS_LAUNCH(false, 2)
+        } else {
+            GDPSO_RS_LAUNCH(false, 1)
+        }
     }
 #undef GDPSO_RS_LAUNCH
     GDPSO_HIP(hipGetLastError());
@@ -619,12 +689,20 @@ int launch_resident_stage(const ResidentStage *s, hipStream_t stream, int n_imag
 
 }  // namespace gdpso
 
-extern "C" int gdpso_resident_options(int stages, int max_images) {
+extern "C" int gdpso_resident_options(int stages, int max_images, int min_images) {
     using namespace gdpso;
     GDPSO_REQUIRE(stages >= 0 && stages <= 2, "resident_options: stages must be 0, 1 or 2");
-    GDPSO_REQUIRE(max_images >= 0, "resident_options: max_images must be 0 (keep) or a batch size");
+    GDPSO_REQUIRE(max_images >= 0 && min_images >= 0, "resident_options: max_images / min_images must be 0 (keep) or a batch size");
+    if (min_images > 0) g_rs_min_images = min_images;
     g_rs_enabled = stages != 0;
     g_rs_stage2 = stages == 2;
     if (max_images > 0) g_rs_max_images = max_images;
+    return GDPSO_OK;
+}
+
+extern "C" int gdpso_resident_force_images(int images_per_workgroup) {
+    using namespace gdpso;
+    GDPSO_REQUIRE(images_per_workgroup >= 0 && images_per_workgroup <= 2, "resident_force_images: 0 (planner's choice), 1 or 2");
+    g_rs_force_images = images_per_workgroup;
     return GDPSO_OK;
 }

@@ -145,13 +145,13 @@ def plan_options(plan_images: int = 0, splitk: bool = True) -> None:
     check(_lib.lib().gdpso_plan_options(int(plan_images), int(bool(splitk))))
 
 
-def resident_options(stages: int = 2, max_images: int = 0) -> None:
+def resident_options(stages: int = 2, max_images: int = 0, min_images: int = 0) -> None:
     """Switches of the resident stages (gdpso_resident_options; pack the assessor AFTER the call).
     ``stages`` 0: stem and every ResNet stage through the tiled convolution kernels; 1: stem and first stage
-    in one launch with their maps in LDS; 2 (default): the second stage too.  ``max_images`` > 0: largest
-    planned batch that takes the resident kernel (0: keep the current limit).  The paths agree to fp32
-    rounding, not bit for bit."""
-    check(_lib.lib().gdpso_resident_options(int(stages), int(max_images)))
+    in one launch with their maps in LDS; 2 (default): the second stage too.  ``max_images`` / ``min_images``
+    > 0: largest / smallest planned batch that takes the resident kernel (0: keep the current limit; defaults
+    1024 and 64).  The paths agree to fp32 rounding, not bit for bit."""
+    check(_lib.lib().gdpso_resident_options(int(stages), int(max_images), int(min_images)))
 
 
 class _Handle:

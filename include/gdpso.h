@@ -412,12 +412,20 @@ int gdpso_plan_options(int plan_images, int splitk);
  * keep two images' maps in LDS; assessors on 28x28 images only, any element type).  Applies to assessors
  * created and launch plans made from now on.  stages = 0: stem and every stage run through the tiled kernels
  * (A/B runs and tests); 1: the stem and the first stage are resident; 2 (default): the second stage as well.
- * max_images > 0: the largest (planned, see gdpso_plan_options) batch that takes the resident kernel; 0 keeps
- * the current limit (default 1024: larger batches fill the device better with the tiled kernels).  The paths
+ * max_images / min_images > 0: the largest / smallest (planned, see gdpso_plan_options) batch that takes the
+ * resident kernel; 0 keeps the current limit (defaults 1024 and 64: larger batches fill the device better with
+ * the tiled kernels, smaller ones leave most CUs without a workgroup; in between a workgroup takes one image up to
+ * one image per CU, two beyond, and batches of more than two images per CU only when whole rounds of workgroups
+ * come out nearly full).  The paths
  * add a row's products in different orders and agree to fp32 rounding (to the element type's rounding for 16-bit
  * storage).  Environment: GDPSO_STAGE1_RESIDENT (0: none), GDPSO_STAGE2_RESIDENT (0: first stage only),
- * GDPSO_STAGE1_RESIDENT_MAX give the initial values. */
-int gdpso_resident_options(int stages, int max_images);
+ * GDPSO_STAGE1_RESIDENT_MAX, GDPSO_STAGE1_RESIDENT_MIN give the initial values. */
+int gdpso_resident_options(int stages, int max_images, int min_images);
+
+/* No counterpart in the reference: a test aid.  Launch plans made from now on give every workgroup of the
+ * resident launch this many images (1 or 2) whatever the batch size (within the limits of
+ * gdpso_resident_options); 0: the planner chooses again.  The two forms give an image the same bits. */
+int gdpso_resident_force_images(int images_per_workgroup);
 
 /* No counterpart in the reference: the tile shape (64, 32 or 16, as in gdpso_conv_probe) a convolution layer
  * would run with as a step of a chained launch over n_images images with `teams` (1 or 2) teams per XCD, or 0

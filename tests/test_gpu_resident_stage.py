@@ -16,9 +16,9 @@ def eng():
     return importlib.import_module("gan-discovery-pso_amd.engine")
 
 
-def _logits(eng, synth, model, x, resident, max_images=1024, n_class=8, dtype="f32"):
+def _logits(eng, synth, model, x, resident, max_images=1024, n_class=8, dtype="f32", min_images=1):
     dev = torch.device("cuda:0")
-    eng.resident_options(int(resident), max_images)
+    eng.resident_options(int(resident), max_images, min_images)
     try:
         ass = eng.PackedAssessor(synth.resnet_state(model, 1, n_class, seed=12), dev, img_side=28, dtype=dtype)
         gen = eng.PackedGenerator(synth.generator_state(10, 1, 64, seed=11), dev, dtype=dtype)
@@ -28,7 +28,7 @@ def _logits(eng, synth, model, x, resident, max_images=1024, n_class=8, dtype="f
             _, logits = ev.assess(x, eng.FitnessSpec(class_index=0), want_logits=True)
             out.append(logits.cpu().numpy().copy())
     finally:
-        eng.resident_options(2, 1024)
+        eng.resident_options(2, 1024, 64)
     np.testing.assert_array_equal(out[1], out[0])
     return out[0]
 
@@ -38,7 +38,7 @@ def _images(n, seed=5):
 
 
 @pytest.mark.parametrize("model,n", [("ResNet50", 512), ("ResNet50", 1), ("ResNet50", 2), ("ResNet50", 37), ("ResNet50", 301),
-                                     ("ResNet50", 1024), ("ResNet101", 128), ("ResNet152", 64)])
+                                     ("ResNet50", 192), ("ResNet50", 257), ("ResNet50", 1024), ("ResNet50", 1001), ("ResNet101", 128), ("ResNet152", 64)])
 def test_resident_stage_matches_tiled_kernels(eng, synth, model, n):
     x = _images(n)
     tiled = _logits(eng, synth, model, x, resident=0)
@@ -48,7 +48,8 @@ def test_resident_stage_matches_tiled_kernels(eng, synth, model, n):
         assert np.isfinite(resident).all()
         np.testing.assert_allclose(resident, tiled, rtol=1e-4, atol=2e-4)
         assert not np.array_equal(resident, tiled) or n < 8  # (the other path did run: the sums are ordered differently)
-    assert not np.array_equal(first, both) or n < 8
+    # (the second stage rides along from 160 images on: GDPSO_STAGE2_RESIDENT_MIN)
+    assert np.array_equal(first, both) == (n < 160)
 
 
 @pytest.mark.parametrize("dtype,bar", [("bf16", 0.6), ("f16", 0.08)])
@@ -97,8 +98,27 @@ def test_an_image_gets_the_same_bits_in_any_batch(eng, synth):
     np.testing.assert_array_equal(odd, whole[1:66])
 
 
-def test_limit_sends_large_batches_to_the_tiled_kernels(eng, synth):
+def test_limits_send_batches_to_the_tiled_kernels(eng, synth):
+    """Above max_images, below min_images and at a batch of one and a half rounds of workgroups (768 images on 256
+    CUs) the tiled kernels run; one image and two images a workgroup give a row the same bits."""
     x = _images(64)
     tiled = _logits(eng, synth, "ResNet50", x, resident=0)
-    limited = _logits(eng, synth, "ResNet50", x, resident=2, max_images=32)
-    np.testing.assert_array_equal(limited, tiled)
+    np.testing.assert_array_equal(_logits(eng, synth, "ResNet50", x, resident=2, max_images=32), tiled)
+    np.testing.assert_array_equal(_logits(eng, synth, "ResNet50", x, resident=2, min_images=65), tiled)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    x = _images(3 * cus)
+    np.testing.assert_array_equal(_logits(eng, synth, "ResNet50", x, resident=2, max_images=8 * cus), _logits(eng, synth, "ResNet50", x, resident=0))
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_one_and_two_images_a_workgroup_give_the_same_bits(eng, synth, dtype):
+    lib = importlib.import_module("gan-discovery-pso_amd._lib")
+    x = _images(161)
+    out = []
+    for images in (1, 2):
+        lib.check(lib.lib().gdpso_resident_force_images(images))
+        try:
+            out.append(_logits(eng, synth, "ResNet50", x, resident=2, dtype=dtype))
+        finally:
+            lib.check(lib.lib().gdpso_resident_force_images(0))
+    np.testing.assert_array_equal(out[0], out[1])
