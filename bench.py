@@ -450,8 +450,10 @@ def main():
                     f"neither roof is near (matrix pipe {achieved / peak:.3f} of its peak, HBM {tb_per_s / 8.0:.3f} of 8 TB/s on the algorithmic bytes): "
                     "per-tile and per-step fixed costs (prologue, hand-off between dependent layers, operand fetch, epilogue); "
                     "`frac` prices the launches against the 16-bit MFMA peak all the same",
-                    "kernel": f"conv_chain_kernel (the ResNet stages behind the first in one persistent launch) / conv_gemm_kernel / conv_gemm_pair_kernel / "
-                              f"conv_gemm_fused_kernel, all instantiations: one tile code ({args.dtype}-input MFMA implicit GEMM)",
+                    "kernel": f"every convolution launch of an iteration ({args.dtype}-input MFMA): conv_chain_kernel (the late ResNet stages in one "
+                              "persistent launch of the implicit-GEMM tile code), stage_resident_kernel (stem + first two stages, two images' maps "
+                              "resident in a workgroup's LDS; 28x28 images) and conv_gemm_kernel / _pair / _fused (the same tile code, one launch a "
+                              "layer: the generator, and whatever the two above do not cover at this size)",
                     "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic,
                     "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE" + (", profiles/" + traffic_file if traffic_file else "; no PMC summary of this configuration") + ")",

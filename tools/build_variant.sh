@@ -8,5 +8,5 @@ NAME=$1
 shift
 cd "$(dirname "$0")/../gan-discovery-pso_amd/csrc"
 /opt/rocm/bin/hipcc -x hip -c conv_gemm.hip -o build/conv_gemm_$NAME.o --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off "$@"
-/opt/rocm/bin/hipcc -shared -o ../../tools/libgdpso_$NAME.so build/pack.o build/conv_gemm_$NAME.o build/nets.o build/pso.o build/vq.o --offload-arch=gfx950
+/opt/rocm/bin/hipcc -shared -o ../../tools/libgdpso_$NAME.so build/pack.o build/conv_gemm_$NAME.o build/nets.o build/stage_resident.o build/pso.o build/vq.o --offload-arch=gfx950
 echo tools/libgdpso_$NAME.so

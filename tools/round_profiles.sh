@@ -12,9 +12,9 @@ bash tools/refresh_profiles.sh ${TAG}
 cp gpurun_out/refresh_${TAG}/final/* $OUT/
 bash tools/refresh_profiles.sh ${TAG}_bf16 --dtype bf16 --z-dim 100
 cp gpurun_out/refresh_${TAG}_bf16/final/* $OUT/
-timeout -k 10 200 python3 tools/chain_probe.py 512 18 f32 > $OUT/${TAG}_chain_steps.txt 2> $OUT/chain_f32.err
+timeout -k 10 200 python3 tools/chain_probe.py 512 6 f32 > $OUT/${TAG}_chain_steps.txt 2> $OUT/chain_f32.err
 echo "chain probe f32 done"
-timeout -k 10 200 python3 tools/chain_probe.py 512 18 bf16 > $OUT/${TAG}_bf16_chain_steps.txt 2> $OUT/chain_bf16.err
+timeout -k 10 200 python3 tools/chain_probe.py 512 6 bf16 > $OUT/${TAG}_bf16_chain_steps.txt 2> $OUT/chain_bf16.err
 echo "chain probe bf16 done"
 timeout -k 10 200 python3 tools/iter_ramp.py 100 > $OUT/${TAG}_iter_ramp.txt 2> $OUT/iter_ramp.err
 echo "iteration ramp done"

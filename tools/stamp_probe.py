@@ -21,7 +21,7 @@ CSRC = os.path.join(ROOT, "gan-discovery-pso_amd", "csrc")
 
 
 def build():
-    srcs = ["pack.cpp", "conv_gemm.hip", "nets.hip", "pso.hip", "vq.hip"]
+    srcs = ["pack.cpp", "conv_gemm.hip", "nets.hip", "stage_resident.hip", "pso.hip", "vq.hip"]
     cmd = (["/opt/rocm/bin/hipcc", "-shared", "-o", LIB, "-x", "hip"] + [os.path.join(CSRC, s) for s in srcs] +
            ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-DGDPSO_STAMPS"])
     if os.environ.get("GDPSO_SKIP_BITS"):  # 1: no MFMAs, 2: no global loads, 4: no LDS stores in the K loop (sum them)
