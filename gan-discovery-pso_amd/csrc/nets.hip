@@ -214,12 +214,15 @@ constexpr int GL_MAX_KSTEPS = 8;  // cin <= 128
 
 template <typename E>
 __global__ __launch_bounds__(512) void gen_last_mfma_kernel(const E *__restrict__ a2, const float *__restrict__ w5,
-                                                            float bias, int hin, int cin, float *__restrict__ img,
+                                                            float bias, int hin, int cin, int band, float *__restrict__ img,
                                                             float *__restrict__ img01, const float *__restrict__ target,
                                                             float *__restrict__ mse, FastDiv div_c4, FastDiv div_side) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int side = 2 * hin, npix = side * side, nin = hin * hin;
-    const int nblk = (nin + 15) / 16, lda = cin + 4;
+    const int side = 2 * hin, npix = side * side;
+    // The input map is walked in bands of `band` rows (all of it when it fits: the 14x14 map of the reference's
+    // generator; the 32x32 map of the 64x64 one in bands): a band's rows plus one row either side are staged,
+    // multiplied, and the output rows 2 r0 .. 2 r1 - 1 of the band gathered into the image.
+    const int brows = band >= hin ? hin : band + 2, nblk = (brows * hin + 15) / 16, lda = cin + 4;
     // n / d by multiply-shift (FastDiv): the chip has no integer divide
     auto fdiv = [](int v, FastDiv f) { return (int)(((unsigned long long)(unsigned)v * f.mul) >> f.shift); };
     float *s_img = smem;                    // [npix]
@@ -227,52 +230,62 @@ __global__ __launch_bounds__(512) void gen_last_mfma_kernel(const E *__restrict_
     float *s_c = s_red + 32;                // [nblk * 16][16]
     float *s_a2 = s_c + nblk * 16 * 16;     // [nblk * 16][lda]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = blockIdx.x;
-    const E *src = a2 + (size_t)n * nin * cin;
+    const E *src = a2 + (size_t)n * hin * hin * cin;
     const int c4 = cin / 4;
-    for (int i = tid; i < nblk * 16 * c4; i += 512) {
-        const int r = fdiv(i, div_c4), c = (i - r * c4) * 4;
-        f32x4_t v = 0.f;
-        if (r < nin) v = load4<E>(&src[(size_t)r * cin + c]);
-        *(f32x4_t *)&s_a2[r * lda + c] = v;
-    }
     // W fragments: column l&15 is the kernel position ky*4+kx, stored as w5[position][channel]
     const int lrow = lane & 15, lk = lane >> 4, ksteps = cin / 16;
     f32x4_t bfrag[GL_MAX_KSTEPS];
 #pragma unroll
     for (int j = 0; j < GL_MAX_KSTEPS; ++j)
         bfrag[j] = j < ksteps ? *(const f32x4_t *)&w5[(size_t)lrow * cin + 16 * j + 4 * lk] : (f32x4_t)0.f;
-    __syncthreads();
-    for (int b = wave; b < nblk; b += 8) {
-        f32x4_t acc = 0.f;
-        const float *pa = s_a2 + (b * 16 + lrow) * lda + 4 * lk;
-#pragma unroll
-        for (int j = 0; j < GL_MAX_KSTEPS; ++j) {
-            if (j < ksteps) {
-                const f32x4_t av = *(const f32x4_t *)(pa + 16 * j);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bfrag[j][s], acc, 0, 0, 0);
-            }
+    for (int r0 = 0; r0 < hin; r0 += band) {
+        const int r1 = min(r0 + band, hin);
+        const int lo = max(r0 - 1, 0), hi = min(r1 + 1, hin), npx = (hi - lo) * hin;  // staged rows [lo, hi)
+        if (r0 > 0) __syncthreads();  // the previous band's gather has read s_c
+        for (int i = tid; i < nblk * 16 * c4; i += 512) {
+            const int r = fdiv(i, div_c4), c = (i - r * c4) * 4;
+            f32x4_t v = 0.f;
+            if (r < npx) v = load4<E>(&src[(size_t)(lo * hin + r) * cin + c]);
+            *(f32x4_t *)&s_a2[r * lda + c] = v;
         }
+        __syncthreads();
+        for (int b = wave; b * 16 < npx; b += 8) {
+            f32x4_t acc = 0.f;
+            const float *pa = s_a2 + (b * 16 + lrow) * lda + 4 * lk;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s_c[(b * 16 + 4 * lk + r) * 16 + lrow] = acc[r];
+            for (int j = 0; j < GL_MAX_KSTEPS; ++j) {
+                if (j < ksteps) {
+                    const f32x4_t av = *(const f32x4_t *)(pa + 16 * j);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bfrag[j][s], acc, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_c[(b * 16 + 4 * lk + r) * 16 + lrow] = acc[r];
+        }
+        __syncthreads();
+        // the four contributions of every output pixel of the band's rows
+        for (int i = 2 * r0 * side + tid; i < 2 * r1 * side; i += 512) {
+            const int oy = fdiv(i, div_side), ox = i - oy * side;
+            const int py = oy & 1, my = oy >> 1, px = ox & 1, mxx = ox >> 1;
+            // (input offset, kernel index) = (0, 1), (-1, 3) for even rows; (0, 2), (+1, 0) for odd; same along x
+            const int iy1 = my + (py ? 1 : -1), ky0 = py ? 2 : 1, ky1 = py ? 0 : 3;
+            const int ix1 = mxx + (px ? 1 : -1), kx0 = px ? 2 : 1, kx1 = px ? 0 : 3;
+            const bool yok = (unsigned)iy1 < (unsigned)hin, xok = (unsigned)ix1 < (unsigned)hin;
+            const float t00 = s_c[((my - lo) * hin + mxx) * 16 + ky0 * 4 + kx0];
+            const float t01 = xok ? s_c[((my - lo) * hin + ix1) * 16 + ky0 * 4 + kx1] : 0.f;
+            const float t10 = yok ? s_c[((iy1 - lo) * hin + mxx) * 16 + ky1 * 4 + kx0] : 0.f;
+            const float t11 = (yok && xok) ? s_c[((iy1 - lo) * hin + ix1) * 16 + ky1 * 4 + kx1] : 0.f;
+            s_img[i] = (t00 + t01) + (t10 + t11);
+        }
     }
     __syncthreads();
-    // gather the four contributions of every output pixel, bias + tanh, per-image min / max
+    // bias + tanh, per-image min / max
     float mn = INFINITY, mx = -INFINITY, se = 0.f;
     float *dst = img ? img + (size_t)n * npix : nullptr;
     const float *tg = target ? target + (size_t)n * npix : nullptr;
     for (int i = tid; i < npix; i += 512) {
-        const int oy = fdiv(i, div_side), ox = i - oy * side;
-        const int py = oy & 1, my = oy >> 1, px = ox & 1, mxx = ox >> 1;
-        // (input offset, kernel index) = (0, 1), (-1, 3) for even rows; (0, 2), (+1, 0) for odd; same along x
-        const int iy1 = my + (py ? 1 : -1), ky0 = py ? 2 : 1, ky1 = py ? 0 : 3;
-        const int ix1 = mxx + (px ? 1 : -1), kx0 = px ? 2 : 1, kx1 = px ? 0 : 3;
-        const bool yok = (unsigned)iy1 < (unsigned)hin, xok = (unsigned)ix1 < (unsigned)hin;
-        const float t00 = s_c[(my * hin + mxx) * 16 + ky0 * 4 + kx0];
-        const float t01 = xok ? s_c[(my * hin + ix1) * 16 + ky0 * 4 + kx1] : 0.f;
-        const float t10 = yok ? s_c[(iy1 * hin + mxx) * 16 + ky1 * 4 + kx0] : 0.f;
-        const float t11 = (yok && xok) ? s_c[(iy1 * hin + ix1) * 16 + ky1 * 4 + kx1] : 0.f;
-        const float v = tanhf(((t00 + t01) + (t10 + t11)) + bias);
+        const float v = tanhf(s_img[i] + bias);
         s_img[i] = v;
         mn = fminf(mn, v);
         mx = fmaxf(mx, v);
@@ -874,11 +887,18 @@ extern "C" int gdpso_generator_forward(const gdpso_generator *g, void *stream_, 
     const int hin = 2 * g->k1;
     const size_t base = ((size_t)g->side * g->side + 32) * sizeof(float);
     const size_t staged = base + (size_t)hin * hin * g->features * sizeof(float);
-    const int nblk = (hin * hin + 15) / 16;
-    const size_t mfma_lds = base + ((size_t)nblk * 16 * 16 + (size_t)nblk * 16 * (g->features + 4)) * sizeof(float);
+    // the MFMA form stages bands of the input map: the whole map when it fits half a CU's LDS (two workgroups a CU),
+    // else the fewest bands that do; a band's rows and one either side, as 16-row blocks of fp32 rows padded by 4
+    auto mfma_lds_of = [&](int band) {
+        const int nblk = ((band >= hin ? hin : band + 2) * hin + 15) / 16;
+        return base + ((size_t)nblk * 16 * 16 + (size_t)nblk * 16 * (g->features + 4)) * sizeof(float);
+    };
+    int band = hin;
+    for (int parts = 1; parts <= hin && mfma_lds_of(band) > std::min<size_t>(g->last_mfma_lds_max, 78 * 1024); ++parts) band = ceil_div(hin, parts);
+    const size_t mfma_lds = mfma_lds_of(band);
     if (g->last_mfma && mfma_lds <= g->last_mfma_lds_max)
         GDPSO_WITH_DTYPE(g->dtype, hipLaunchKernelGGL(gen_last_mfma_kernel<E>, dim3(n), dim3(512), mfma_lds, stream, (const E *)a2, g->w5,
-                                                      g->b5, hin, g->features, img, img01, target, mse,
+                                                      g->b5, hin, g->features, band, img, img01, target, mse,
                                                       fast_div_for((unsigned)(g->features / 4)), fast_div_for((unsigned)(2 * hin))));
     else if (staged <= 64 * 1024)
         GDPSO_WITH_DTYPE(g->dtype, hipLaunchKernelGGL((gen_last_kernel<true, E>), dim3(n), dim3(512), staged, stream, (const E *)a2, g->w5,
