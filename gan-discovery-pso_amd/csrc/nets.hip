@@ -421,11 +421,14 @@ constexpr int STEM_KSTEPS = 13;  // ceil(49 / 4)
 template <typename E>
 __global__ __launch_bounds__(512) void stem_mfma_kernel(const float *__restrict__ img01, const float *__restrict__ w,
                                                         const float *__restrict__ scale, const float *__restrict__ shift,
-                                                        int side, int ho, int hp, int ps, FastDiv div_ho, FastDiv div_hp,
+                                                        int side, int ho, int hp, int ps, int band, FastDiv div_ho, FastDiv div_hp,
                                                         E *__restrict__ out, f32x4 *__restrict__ zero, int zero_quads) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     stem_zero(zero, zero_quads, (int)blockIdx.x, (int)gridDim.x);
-    const int prows = side + 6, npx = ho * ho, nblk = (npx + 15) / 16;
+    // The pooled rows are walked in bands of `band` (all of them when the whole convolution image fits: 28x28
+    // inputs; larger inputs in bands): a band's convolution rows 2 pr0 - 1 .. 2 pr1 - 1 are computed into LDS, pooled
+    // and written; the rows two neighbouring bands both need are computed twice.
+    const int prows = side + 6;
     // n / d by multiply-shift (FastDiv): the chip has no integer divide
     auto fdiv = [](int v, FastDiv f) { return (int)(((unsigned long long)(unsigned)v * f.mul) >> f.shift); };
     constexpr int LDC = 64 + 4;
@@ -464,44 +467,48 @@ __global__ __launch_bounds__(512) void stem_mfma_kernel(const float *__restrict_
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) bw[t][cb] = k < 49 ? s_conv[k * LDW + cb * 16 + lrow] : 0.f;
     }
-    __syncthreads();
-    for (int b = wave; b < nblk; b += 8) {
-        const int px = min(b * 16 + lrow, npx - 1);  // rows past the image repeat the last pixel; they are never read back
-        const int y = fdiv(px, div_ho), x = px - y * ho;
-        const float *base = s_img + (2 * y) * ps + 2 * x;  // padded coordinates: +3 - 3
-        float av[STEM_KSTEPS];
+    for (int pr0 = 0; pr0 < hp; pr0 += band) {
+        const int pr1 = min(pr0 + band, hp);
+        const int cr0 = max(2 * pr0 - 1, 0), cr1 = min(2 * pr1 - 1, ho - 1), npx = (cr1 - cr0 + 1) * ho;  // conv rows [cr0, cr1]
+        __syncthreads();  // the weights have left s_conv / the previous band's pooling has read it
+        for (int b = wave; b * 16 < npx; b += 8) {
+            const int px = min(b * 16 + lrow, npx - 1);  // rows past the band repeat its last pixel; they are never read back
+            const int yl = fdiv(px, div_ho), x = px - yl * ho, y = cr0 + yl;
+            const float *base = s_img + (2 * y) * ps + 2 * x;  // padded coordinates: +3 - 3
+            float av[STEM_KSTEPS];
 #pragma unroll
-        for (int t = 0; t < STEM_KSTEPS; ++t) av[t] = base[koff[t]];
-        f32x4_t acc[4];
+            for (int t = 0; t < STEM_KSTEPS; ++t) av[t] = base[koff[t]];
+            f32x4_t acc[4];
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) acc[cb] = 0.f;
+            for (int cb = 0; cb < 4; ++cb) acc[cb] = 0.f;
 #pragma unroll
-        for (int t = 0; t < STEM_KSTEPS; ++t)
+            for (int t = 0; t < STEM_KSTEPS; ++t)
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bw[t][cb], acc[cb], 0, 0, 0);
+                for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bw[t][cb], acc[cb], 0, 0, 0);
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
+            for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                s_conv[(b * 16 + 4 * lk + r) * LDC + cb * 16 + lrow] = fmaxf(acc[cb][r] * sc[cb] + sh[cb], 0.f);
-    }
-    __syncthreads();
-    // MaxPool2d(3, s2, p1); consecutive threads take consecutive channels
-    for (int e = tid; e < hp * hp * 64; e += 512) {
-        const int c = e & 63, pp = e >> 6, pr = fdiv(pp, div_hp), pc = pp - pr * hp;
-        float m = -INFINITY;
-#pragma unroll
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int cy = 2 * pr + dy;
-            if ((unsigned)cy >= (unsigned)ho) continue;
-#pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int cx = 2 * pc + dx;
-                if ((unsigned)cx >= (unsigned)ho) continue;
-                m = fmaxf(m, s_conv[(cy * ho + cx) * LDC + c]);
-            }
+                for (int r = 0; r < 4; ++r)
+                    s_conv[(b * 16 + 4 * lk + r) * LDC + cb * 16 + lrow] = fmaxf(acc[cb][r] * sc[cb] + sh[cb], 0.f);
         }
-        out[((size_t)n * hp * hp + pp) * 64 + c] = (E)m;
+        __syncthreads();
+        // MaxPool2d(3, s2, p1) of the band's pooled rows; consecutive threads take consecutive channels
+        for (int e = tid; e < (pr1 - pr0) * hp * 64; e += 512) {
+            const int c = e & 63, pl = e >> 6, prl = fdiv(pl, div_hp), pc = pl - prl * hp, pr = pr0 + prl;
+            float m = -INFINITY;
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int cy = 2 * pr + dy;
+                if ((unsigned)cy >= (unsigned)ho) continue;
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int cx = 2 * pc + dx;
+                    if ((unsigned)cx >= (unsigned)ho) continue;
+                    m = fmaxf(m, s_conv[((cy - cr0) * ho + cx) * LDC + c]);
+                }
+            }
+            out[((size_t)n * hp * hp + (size_t)pr * hp + pc) * 64 + c] = (E)m;
+        }
     }
 }
 
@@ -1329,16 +1336,36 @@ static int assessor_forward_impl(const gdpso_assessor *a, void *stream_, int n, 
     f32x4 *const ctl_zero = use_chain ? (f32x4 *)(ws + L.chain_ctl) : nullptr;
     const int ctl_quads = (int)(chain_ctl_bytes() / 16);
     const int mps = (a->side + 6 + 3) / 4 * 4;
-    const size_t mfma_smem = ((size_t)(a->side + 6) * mps + (size_t)((a->ho * a->ho + 15) / 16 * 16) * 68) * sizeof(float);
+    // the MFMA stem keeps a band of pooled rows' convolution rows in LDS: all rows when they fit beside the padded
+    // image (28x28 inputs: 57 KB), else the largest band that fits GDPSO_STEM_LDS_KB
+    auto stem_lds_of = [&](int band) {
+        const int crows = band >= a->hp ? a->ho : 2 * band + 1;
+        return ((size_t)(a->side + 6) * mps + (size_t)((crows * a->ho + 15) / 16 * 16) * 68) * sizeof(float);
+    };
+    static const size_t stem_lds_max = [] {
+        const char *e = getenv("GDPSO_STEM_LDS_KB");
+        size_t kb = e ? (size_t)atoi(e) : 100;  // (64x64 inputs: bands of 4 pooled rows; measured 64 / 82 / 100 / 152: 0.719 / 0.717 / 0.715 / 0.714 ms per iteration of 256)
+        if (kb > 64) {
+            hipError_t e1 = hipFuncSetAttribute((const void *)stem_mfma_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+            hipError_t e2 = hipFuncSetAttribute((const void *)stem_mfma_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+            hipError_t e3 = hipFuncSetAttribute((const void *)stem_mfma_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+            if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) kb = 64;
+            (void)hipGetLastError();
+        }
+        return std::min<size_t>(kb, 152) * 1024;
+    }();
+    int mfma_band = a->hp;
+    while (mfma_band > 1 && stem_lds_of(mfma_band) > stem_lds_max) --mfma_band;
+    const size_t mfma_smem = stem_lds_of(mfma_band);
     int rc;
     if (L.resident) {
-        // stem and first stage in one launch; its output lies where the tiled kernels would have left it (in x
+        // stem and first stages in one launch; its output lies where the tiled kernels would have left it (in x
         // after an even number of blocks, else in y)
         if (L.chain_first % 2 == 1) std::swap(x, y);
         if ((rc = launch_resident_stage(a->resident, stream, n, L.resident_images, L.resident_second, img01, x, ctl_zero, ctl_quads))) return rc;
-    } else if (stem_mfma && mfma_smem <= 64 * 1024) {
+    } else if (stem_mfma && mfma_smem <= stem_lds_max) {
         GDPSO_WITH_DTYPE(a->dtype, hipLaunchKernelGGL(stem_mfma_kernel<E>, dim3(n), dim3(512), mfma_smem, stream, img01, a->stem_w,
-                                                      a->stem_scale, a->stem_shift, a->side, a->ho, a->hp, mps,
+                                                      a->stem_scale, a->stem_shift, a->side, a->ho, a->hp, mps, mfma_band,
                                                       fast_div_for((unsigned)a->ho), fast_div_for((unsigned)a->hp), (E *)x, ctl_zero, ctl_quads));
     } else {
         const int rows = 2 * a->stem_band + 1;
