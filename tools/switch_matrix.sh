@@ -18,4 +18,8 @@ run GDPSO_SPLITK_FUSED_MAX=8 GDPSO_CONV_TILE32=0
 run GDPSO_CONV_SNAKE=0
 run GDPSO_CONV_CHAIN=0
 run GDPSO_CHAIN_TEAMS=2
+run GDPSO_STAGE1_RESIDENT=0
+run GDPSO_STAGE2_RESIDENT=0
+run GDPSO_STAGE1_RESIDENT_MIN=1 GDPSO_STAGE2_RESIDENT_MIN=1
+run GDPSO_STEM_LDS_KB=64 GDPSO_STAGE1_RESIDENT=0
 cat $OUT
