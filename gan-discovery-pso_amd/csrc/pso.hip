@@ -7,6 +7,7 @@
 // for identical fitness decisions.  These kernels are HBM/latency bound (a few hundred
 // bytes per particle): elements are mapped to consecutive lanes for coalesced access.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -158,6 +159,34 @@ __global__ __launch_bounds__(256) void candidate_kernel(gdpso_swarm s, int itera
 // inertia decay (:178-179) and the early-stopping test (:186-188).  One workgroup; every
 // rank runs it on identical inputs and reaches identical decisions.
 // One thread: the decision part of update_global_best.  Returns the winning slot or -1.
+// Bookkeeping of a decision: `best` is the global best value after it, best_slot >= 0 when a candidate took over
+// (its global index best_idx), cur / n_imp / w the control block's values before it.  Returns the inertia weight
+// the move of this iteration uses.
+__device__ __forceinline__ double record_global_best(const gdpso_swarm &s, int iteration, int schedule_inertia, int early_stopping,
+                                                     double tolerance, float cur, float best, int best_slot, int best_idx, int n_imp,
+                                                     double w) {
+    if (best_slot >= 0) {
+        if (isinf(cur) && cur > 0.f)
+            s.g_best_val[n_imp - 1] = best;  // the first improvement overwrites the inf
+        else
+            s.g_best_val[n_imp++] = best;
+        s.ctrl[GDPSO_CTRL_GBEST_VAL] = (double)best;
+        s.ctrl[GDPSO_CTRL_GBEST_IDX] = (double)best_idx;
+        s.ctrl[GDPSO_CTRL_N_IMPROVE] = (double)n_imp;
+    }
+    s.g_best_val_dummy[iteration - 1] = best;
+    if (iteration > 1 && schedule_inertia) {
+        w = 0.99 * w;
+        s.ctrl[GDPSO_CTRL_W] = w;
+    }
+    if (iteration > 2 && n_imp > 2 && early_stopping) {
+        const float diff = fabsf(s.g_best_val[n_imp - 1] - s.g_best_val[n_imp - 2]);
+        if (diff < (float)tolerance) s.ctrl[GDPSO_CTRL_STOP_ITER] = (double)iteration;
+    }
+    s.ctrl[GDPSO_CTRL_ITERS_DONE] = (double)iteration;
+    return w;
+}
+
 __device__ int decide_global_best(const gdpso_swarm &s, int iteration, int schedule_inertia, int early_stopping,
                                   double tolerance) {
     float cur = (float)s.ctrl[GDPSO_CTRL_GBEST_VAL];
@@ -175,23 +204,8 @@ __device__ int decide_global_best(const gdpso_swarm &s, int iteration, int sched
             best_idx = idx;
         }
     }
-    int n_imp = (int)s.ctrl[GDPSO_CTRL_N_IMPROVE];
-    if (best_slot >= 0) {
-        if (isinf(cur) && cur > 0.f)
-            s.g_best_val[n_imp - 1] = best;  // the first improvement overwrites the inf
-        else
-            s.g_best_val[n_imp++] = best;
-        s.ctrl[GDPSO_CTRL_GBEST_VAL] = (double)best;
-        s.ctrl[GDPSO_CTRL_GBEST_IDX] = (double)best_idx;
-        s.ctrl[GDPSO_CTRL_N_IMPROVE] = (double)n_imp;
-    }
-    s.g_best_val_dummy[iteration - 1] = best;
-    if (iteration > 1 && schedule_inertia) s.ctrl[GDPSO_CTRL_W] = 0.99 * s.ctrl[GDPSO_CTRL_W];
-    if (iteration > 2 && n_imp > 2 && early_stopping) {
-        const float diff = fabsf(s.g_best_val[n_imp - 1] - s.g_best_val[n_imp - 2]);
-        if (diff < (float)tolerance) s.ctrl[GDPSO_CTRL_STOP_ITER] = (double)iteration;
-    }
-    s.ctrl[GDPSO_CTRL_ITERS_DONE] = (double)iteration;
+    record_global_best(s, iteration, schedule_inertia, early_stopping, tolerance, cur, best, best_slot, best_idx,
+                       (int)s.ctrl[GDPSO_CTRL_N_IMPROVE], s.ctrl[GDPSO_CTRL_W]);
     return best_slot;
 }
 
@@ -254,10 +268,9 @@ __device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {
 //   best_soci = (w_soci * r2) * (p_best_pos - pos)      (r2 pairs with the PERSONAL best)
 //   vel = (inertia + best_soci) + best_cogn ;  pos = pos + vel
 // r1, r2 are scalars per particle.  One thread per (particle, dimension) element.
-__device__ __forceinline__ void move_element(const gdpso_swarm &s, int iteration, long e, double w, double w_cogn,
-                                             double w_soci, const double *__restrict__ rnd, uint64_t seed, int f32_terms) {
-    const int p = (int)(e / s.d), k = (int)(e - (long)p * s.d);
-    double r1, r2;
+// The draws of particle p at `iteration`: the host's (rnd) or Philox's.
+__device__ __forceinline__ void move_draws(const gdpso_swarm &s, int iteration, int p, const double *__restrict__ rnd, uint64_t seed,
+                                           double &r1, double &r2) {
     if (rnd) {
         r1 = rnd[2 * (size_t)p];
         r2 = rnd[2 * (size_t)p + 1];
@@ -267,7 +280,11 @@ __device__ __forceinline__ void move_element(const gdpso_swarm &s, int iteration
         r1 = u53(o[0], o[1]);
         r2 = u53(o[2], o[3]);
     }
-    const double x = s.pos[e], v = s.vel[e];
+}
+
+// One element's new velocity; the new position is x + it.
+__device__ __forceinline__ double move_velocity(double x, double v, double pbest, double gbest, double r1, double r2, double w,
+                                                double w_cogn, double w_soci, int f32_terms) {
     const double inertia = w * v;
     const double c1 = w_cogn * r1;
     const double c2 = w_soci * r2;
@@ -276,13 +293,22 @@ __device__ __forceinline__ void move_element(const gdpso_swarm &s, int iteration
         // float32 positions (first move of the inverter variant): numpy keeps float32 for
         // array - array and for python-float * float32-array
         const float xf = (float)x;
-        best_cogn = (double)((float)c1 * ((float)s.gbest_pos[k] - xf));
-        best_soci = (double)((float)c2 * ((float)s.pbest_pos[e] - xf));
+        best_cogn = (double)((float)c1 * ((float)gbest - xf));
+        best_soci = (double)((float)c2 * ((float)pbest - xf));
     } else {
-        best_cogn = c1 * (s.gbest_pos[k] - x);
-        best_soci = c2 * (s.pbest_pos[e] - x);
+        best_cogn = c1 * (gbest - x);
+        best_soci = c2 * (pbest - x);
     }
-    const double nv = (inertia + best_soci) + best_cogn;
+    return (inertia + best_soci) + best_cogn;
+}
+
+__device__ __forceinline__ void move_element(const gdpso_swarm &s, int iteration, long e, double w, double w_cogn,
+                                             double w_soci, const double *__restrict__ rnd, uint64_t seed, int f32_terms) {
+    const int p = (int)(e / s.d), k = (int)(e - (long)p * s.d);
+    double r1, r2;
+    move_draws(s, iteration, p, rnd, seed, r1, r2);
+    const double x = s.pos[e];
+    const double nv = move_velocity(x, s.vel[e], s.pbest_pos[e], s.gbest_pos[k], r1, r2, w, w_cogn, w_soci, f32_terms);
     const double nx = x + nv;
     s.vel[e] = nv;
     s.pos[e] = nx;
@@ -373,6 +399,140 @@ __device__ __forceinline__ void small_step(const gdpso_swarm &s, int iteration, 
     for (long e = tid; e < nd; e += SMALL_THREADS) move_element(s, iteration, e, w, w_cogn, w_soci, rnd, seed, f32_terms);
 }
 
+// The same step for a single process and at most FAST_ELEMS state elements per thread, arranged so that it has ONE
+// round trip to memory on its critical path instead of six: everything the step reads is requested at entry (fitness
+// and personal-best values, the control block, the old global best, and the position / velocity / personal-best
+// elements the thread will move), the candidate record, the decision and the new global best pass through LDS (they
+// are still written to memory for the host), and the move works on the registers.  Same arithmetic, same results.
+constexpr int FAST_ELEMS = 8, FAST_MAX_D = 1024;
+static bool g_small_fast = [] {
+    const char *e = getenv("GDPSO_SWARM_FAST_STEP");
+    return e ? e[0] != '0' : true;
+}();
+static bool small_step_fast_ok(const gdpso_swarm &s) {
+    return g_small_fast && s.n_ranks == 1 && (long)s.n * s.d <= (long)FAST_ELEMS * SMALL_THREADS && s.d <= FAST_MAX_D;
+}
+
+__device__ __forceinline__ void small_step_fast(const gdpso_swarm &s, int iteration, int schedule_inertia, int early_stopping,
+                                                double tolerance, double w_cogn, double w_soci, const double *__restrict__ rnd,
+                                                uint64_t seed, int f32_terms, unsigned char *s_better, BestRec *s_best, bool in_budget) {
+    __shared__ double s_gbest[FAST_MAX_D];
+    __shared__ double s_w;
+    __shared__ int s_take, s_best_p;
+    const int tid = threadIdx.x, n = s.n, d = s.d;
+    const long nd = (long)n * d;
+    // ---- everything the step reads, requested at once
+    const double stop_at = s.ctrl[GDPSO_CTRL_STOP_ITER];
+    double c_gbest = 0.0, c_nimp = 0.0, c_w = 0.0;
+    if (tid == 0) {
+        c_gbest = s.ctrl[GDPSO_CTRL_GBEST_VAL];
+        c_nimp = s.ctrl[GDPSO_CTRL_N_IMPROVE];
+        c_w = s.ctrl[GDPSO_CTRL_W];
+    }
+    float fit[SMALL_MAX_N / SMALL_THREADS], pbv[SMALL_MAX_N / SMALL_THREADS];
+#pragma unroll
+    for (int i = 0; i < SMALL_MAX_N / SMALL_THREADS; ++i) {
+        const int p = tid + i * SMALL_THREADS;
+        fit[i] = p < n ? s.fitness[p] : 0.f;
+        pbv[i] = p < n ? s.pbest_val[p] : 0.f;
+    }
+    double x[FAST_ELEMS], v[FAST_ELEMS], pb[FAST_ELEMS];
+#pragma unroll
+    for (int i = 0; i < FAST_ELEMS; ++i) {
+        const long e = tid + (long)i * SMALL_THREADS;
+        x[i] = e < nd ? s.pos[e] : 0.0;
+        v[i] = e < nd ? s.vel[e] : 0.0;
+        pb[i] = e < nd ? s.pbest_pos[e] : 0.0;
+    }
+    for (int k = tid; k < d; k += SMALL_THREADS) s_gbest[k] = s.gbest_pos[k];
+    const int stop = (int)stop_at;
+    if (!in_budget || !(stop == 0 || iteration <= stop)) return;  // (uniform over the workgroup)
+    // ---- update_personal_best
+    BestRec r;
+    r.val = INFINITY;
+    r.idx = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < SMALL_MAX_N / SMALL_THREADS; ++i) {
+        const int p = tid + i * SMALL_THREADS;
+        if (p < n) {
+            const bool better = fit[i] < pbv[i];
+            if (better) {
+                pbv[i] = fit[i];
+                s.pbest_val[p] = fit[i];
+            }
+            s_better[p] = better;
+            BestRec c;
+            c.val = pbv[i];
+            c.idx = s.first_index + p;
+            r = better_of(r, c);
+        }
+    }
+    r = wave_best(r);
+    if ((tid & 63) == 0) s_best[tid >> 6] = r;
+    __syncthreads();
+    r = s_best[0];
+#pragma unroll
+    for (int w = 1; w < SMALL_THREADS / 64; ++w) r = better_of(r, s_best[w]);
+    const bool have = r.idx != 0x7fffffff && r.val < INFINITY;
+    // ---- personal-best positions, and the candidate = the best particle's (updated) personal best
+    if (tid == 0) {
+        // update_global_best, inertia decay, early-stopping test: one candidate, this swarm's
+        const float cur = (float)c_gbest;
+        const bool take = have && r.val < cur;
+        s_take = take ? 1 : 0;
+        s_best_p = have ? r.idx - s.first_index : -1;
+        double *rec = cand_row(s, 0);
+        rec[0] = have ? (double)r.val : (double)INFINITY;
+        rec[1] = have ? (double)r.idx : -1.0;
+        s_w = record_global_best(s, iteration, schedule_inertia, early_stopping, tolerance, cur, take ? r.val : cur, take ? 0 : -1,
+                                 take ? r.idx : 0x7fffffff, (int)c_nimp, c_w);
+    }
+    __syncthreads();
+    const int best_p = s_best_p;
+    const bool take = s_take != 0;
+    double *rec = cand_row(s, 0);
+#pragma unroll
+    for (int i = 0; i < FAST_ELEMS; ++i) {
+        const long e = tid + (long)i * SMALL_THREADS;
+        if (e < nd) {
+            const int p = (int)(e / d), k = (int)(e - (long)p * d);
+            if (s_better[p]) {
+                pb[i] = x[i];
+                s.pbest_pos[e] = x[i];
+            }
+            if (p == best_p) {
+                rec[2 + k] = pb[i];
+                if (take) {
+                    s_gbest[k] = pb[i];
+                    s.gbest_pos[k] = pb[i];
+                }
+            }
+        }
+    }
+    if (best_p < 0)
+        for (int k = tid; k < d; k += SMALL_THREADS) rec[2 + k] = 0.0;
+    __syncthreads();
+    // ---- move_particles
+    const double w = s_w;
+#pragma unroll
+    for (int i = 0; i < FAST_ELEMS; ++i) {
+        const long e = tid + (long)i * SMALL_THREADS;
+        if (e < nd) {
+            const int p = (int)(e / d), k = (int)(e - (long)p * d);
+            double r1, r2;
+            move_draws(s, iteration, p, rnd, seed, r1, r2);
+            const double nv = move_velocity(x[i], v[i], pb[i], s_gbest[k], r1, r2, w, w_cogn, w_soci, f32_terms);
+            const double nx = x[i] + nv;
+            s.vel[e] = nv;
+            s.pos[e] = nx;
+            const size_t h = (size_t)iteration * n * d + e;
+            if (s.hist_pos) s.hist_pos[h] = nx;
+            if (s.hist_vel) s.hist_vel[h] = nv;
+        }
+    }
+}
+
+template <bool FAST>
 __global__ __launch_bounds__(SMALL_THREADS) void swarm_step_small_kernel(gdpso_swarm s, int iteration, int schedule_inertia,
                                                                          int early_stopping, double tolerance, double w_cogn,
                                                                          double w_soci, const double *__restrict__ rnd,
@@ -380,6 +540,10 @@ __global__ __launch_bounds__(SMALL_THREADS) void swarm_step_small_kernel(gdpso_s
     __shared__ unsigned char s_better[SMALL_MAX_N];
     __shared__ BestRec s_best[SMALL_THREADS / 64];
     __shared__ int s_take;
+    if constexpr (FAST) {
+        small_step_fast(s, iteration, schedule_inertia, early_stopping, tolerance, w_cogn, w_soci, rnd, seed, f32_terms, s_better, s_best, true);
+        return;
+    }
     if (!running(s.ctrl, iteration)) return;
     small_step(s, iteration, schedule_inertia, early_stopping, tolerance, w_cogn, w_soci, rnd, seed, f32_terms, s_better, s_best,
                &s_take);
@@ -405,12 +569,18 @@ __device__ __forceinline__ bool running_multi(const gdpso_swarm &s, int iteratio
     return iteration <= s.max_iter && running(s.ctrl, iteration);
 }
 
+template <bool FAST>
 __global__ __launch_bounds__(SMALL_THREADS) void swarm_step_small_multi_kernel(SwarmBatch b, int iteration) {
     __shared__ unsigned char s_better[SMALL_MAX_N];
     __shared__ BestRec s_best[SMALL_THREADS / 64];
     __shared__ int s_take;
     const int k = blockIdx.x;
     const gdpso_swarm &s = b.s[k];
+    if constexpr (FAST) {
+        small_step_fast(s, iteration, b.schedule_inertia[k], b.early_stopping[k], b.tolerance[k], b.w_cogn[k], b.w_soci[k], b.rnd[k],
+                        b.seed[k], b.f32_terms[k], s_better, s_best, iteration <= s.max_iter);
+        return;
+    }
     if (!running_multi(s, iteration)) return;
     small_step(s, iteration, b.schedule_inertia[k], b.early_stopping[k], b.tolerance[k], b.w_cogn[k], b.w_soci[k], b.rnd[k],
                b.seed[k], b.f32_terms[k], s_better, s_best, &s_take);
@@ -829,9 +999,14 @@ extern "C" int gdpso_swarm_iterate(const gdpso_swarm *s, const gdpso_generator *
             return rc;
         const double *rnd = r->rand ? r->rand + (size_t)(i - 1) * s->n * 2 : nullptr;
         if (s->n <= SMALL_MAX_N && (long)s->n * s->d <= SMALL_MAX_ELEMS) {
-            hipLaunchKernelGGL(swarm_step_small_kernel, dim3(1), dim3(SMALL_THREADS), 0, (hipStream_t)stream, *s, i,
-                               r->schedule_inertia, r->early_stopping, r->tolerance, r->w_cogn, r->w_soci, rnd, r->seed,
-                               (r->f32_first_move && i == 1) ? 1 : 0);
+            if (small_step_fast_ok(*s))
+                hipLaunchKernelGGL(swarm_step_small_kernel<true>, dim3(1), dim3(SMALL_THREADS), 0, (hipStream_t)stream, *s, i,
+                                   r->schedule_inertia, r->early_stopping, r->tolerance, r->w_cogn, r->w_soci, rnd, r->seed,
+                                   (r->f32_first_move && i == 1) ? 1 : 0);
+            else
+                hipLaunchKernelGGL(swarm_step_small_kernel<false>, dim3(1), dim3(SMALL_THREADS), 0, (hipStream_t)stream, *s, i,
+                                   r->schedule_inertia, r->early_stopping, r->tolerance, r->w_cogn, r->w_soci, rnd, r->seed,
+                                   (r->f32_first_move && i == 1) ? 1 : 0);
             GDPSO_HIP(hipGetLastError());
         } else {
             GDPSO_REQUIRE(gdpso_swarm_scratch_bytes(s->n) <= s->scratch_bytes, "swarm_iterate: scratch too small");
@@ -921,7 +1096,12 @@ extern "C" int gdpso_swarm_iterate_multi(const gdpso_swarm *swarms, const gdpso_
                 }
             }
             if (small) {
-                hipLaunchKernelGGL(swarm_step_small_multi_kernel, dim3(cnt), dim3(SMALL_THREADS), 0, (hipStream_t)stream, b, i);
+                bool fast = true;
+                for (int j = 0; j < cnt; ++j) fast = fast && small_step_fast_ok(swarms[k0 + j]);
+                if (fast)
+                    hipLaunchKernelGGL(swarm_step_small_multi_kernel<true>, dim3(cnt), dim3(SMALL_THREADS), 0, (hipStream_t)stream, b, i);
+                else
+                    hipLaunchKernelGGL(swarm_step_small_multi_kernel<false>, dim3(cnt), dim3(SMALL_THREADS), 0, (hipStream_t)stream, b, i);
             } else {  // large swarms: the multi-workgroup kernels, swarm by swarm
                 for (int j = 0; j < cnt; ++j) {
                     const gdpso_swarm &s = swarms[k0 + j];
