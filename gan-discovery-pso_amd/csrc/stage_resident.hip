@@ -1,29 +1,36 @@
-// First ResNet stage with its activations resident in LDS (gfx950, fp32, 7x7 maps).
+// The assessor's stem and first two ResNet stages with their activations resident in LDS (gfx950, 28x28 images).
 //
-// The bottleneck blocks of the first stage (reference src/pso/util_cnn.py:94, 147-157, 160-190: 1x1 -> 3x3 ->
-// 1x1 convolutions with BatchNorm, the projection shortcut of the first block, residual add, ReLU) work on
-// maps of 7x7 pixels when the assessor sees the reference's 28x28 images.  Rows of different images never
-// interact and an image's maps are small: 49 x 256 floats for a block's output, 49 x 64 for the two
-// intermediates.  One workgroup therefore takes TWO images (98 rows = 7 blocks of 16, 150 KB of the CU's
-// 160 KB of LDS), walks every layer of the stage for them and writes only the stage's output: no
-// intermediate touches HBM, nothing is handed between workgroups, and the stage is one launch of n / 2
-// workgroups (one per CU at the 512 particles of the headline configuration) where the tiled kernels
-// need six launches whose tiles of 64 rows come to 1.5 per CU.
+// The stem (reference src/pso/util_cnn.py:85-88, 103-106) and the bottleneck blocks of the first two stages
+// (:94-95, 147-157, 160-190: 1x1 -> 3x3 -> 1x1 convolutions with BatchNorm, the projection shortcut of a stage's
+// first block, residual add, ReLU) work on maps of 14x14, 7x7 and 4x4 pixels when the assessor sees the
+// reference's 28x28 images.  Rows of different images never interact and an image's maps are small: 49 x 256
+// floats for a block's output in the first stage, 16 x 512 in the second.  One workgroup therefore takes TWO
+// images (98 rows = 7 blocks of 16 on the 7x7 maps, 32 rows = 2 blocks on the 4x4; 150 KB of the CU's 160 KB of
+// LDS), walks the stem and every layer of both stages for them and writes only the second stage's output: no
+// intermediate touches HBM, nothing is handed between workgroups, only workgroup barriers stand between
+// layers, and the launch is n / 2 workgroups (one per CU at the 512 particles of the headline configuration)
+// where the tiled kernels need a launch per layer (tiles of 64 rows: 1.5 per CU in the first stage) or the
+// chained launch a hand-off between workgroups per layer.  Smaller batches give a workgroup ONE image (4 and 1 row
+// blocks) so that every image still has a CU of its own; see resident_stage_images.
 //
 // Arithmetic: v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulation).  The A operand of every
-// layer is read from LDS where the previous layer's epilogue left it (rows padded by 4 floats: conflict-free
-// 16-byte fragment reads); the B operand comes straight from global memory (the stage's weights are 0.85 MB,
+// layer is read from LDS where the previous layer's epilogue left it (rows padded by 16 bytes: conflict-free
+// 16-byte fragment reads); the B operand comes straight from global memory (the two stages' weights are 5.7 MB,
 // resident in every L2) in fragment order: the host packs a layer as [column block of 16][k group of 16][lane][4],
-// so a wave's fragment load is one contiguous KiB, prefetched three k groups ahead.  Lane l of a wave holds
-// A[row l & 15][k] and B[k][column l & 15] for the four k = 16 j + 4 (l >> 4) + s of group j: one 16-byte
-// read of each feeds four MFMAs.  The 3x3 convolution reads its nine taps as nine row offsets into the same
-// LDS map; a tap that leaves the image reads a row of zeros.
+// so a wave's fragment load is one contiguous KiB, prefetched three k groups ahead (six where a group is only
+// eight MFMAs).  Lane l of a wave holds A[row l & 15][k] and B[k][column l & 15] for the four
+// k = 16 j + 4 (l >> 4) + s of group j: one 16-byte read of each feeds four MFMAs.  A 3x3 convolution reads its
+// nine taps as nine row offsets into the same LDS map; a tap that leaves the image reads a row of zeros; the
+// stride-2 layers of the second stage's first block pick their rows the same way.
 //
-// Eight waves: a 64-column layer gives wave w column block w & 3 and every second row block (4 or 3 of the 7);
-// a 256-column layer gives it column blocks 2w, 2w + 1 and all seven row blocks.  Only workgroup barriers
-// between layers.  The sums run over k in another order than the tiled kernels' (groups of 16 interleaved
-// by 4), so the two paths agree to fp32 rounding, not bit for bit; a row's result does not depend on the
-// batch it arrives in nor on its place in the workgroup.
+// Eight waves.  First stage: a 64-column layer gives wave w column block w & 3 and every second row block (4 or 3
+// of the 7); a 256-column layer gives it column blocks 2w, 2w + 1 and all seven row blocks.  Second stage: a
+// 128-column layer gives it column block w, a 512-column layer blocks 4w .. 4w + 3, both row blocks each.  The sums
+// run over k in another order than the tiled kernels' (groups of 16 interleaved by 4), so the two paths agree
+// to fp32 rounding, not bit for bit; a row's result does not depend on the batch it arrives in nor on its place
+// in the workgroup.  What bounds the scheme is the weights' way into the CU: a workgroup reads every weight of a
+// layer for its few rows, 33 GB/s per CU at the second stage's 32 rows; the third stage (2x2 maps: 8 rows) would
+// need 134 GB/s per CU and stays with the chained launch.
 //
 // 16-bit storage (bf16 / fp16): the same kernel with v_mfma_f32_16x16x32_bf16 / _f16; a 16-byte fragment is then
 // eight consecutive k of ONE instruction (a k group is 32 wide), LDS rows are padded by 8 elements, accumulation,
