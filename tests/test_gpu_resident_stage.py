@@ -46,8 +46,12 @@ def _images(n, seed=5):
 
 
 @pytest.mark.parametrize("model,n", [("ResNet50", 512), ("ResNet50", 1), ("ResNet50", 2), ("ResNet50", 37), ("ResNet50", 301),
-                                     ("ResNet50", 192), ("ResNet50", 257), ("ResNet50", 1024), ("ResNet50", 1001), ("ResNet101", 128), ("ResNet152", 64)])
+                                     ("ResNet50", 192), ("ResNet50", 257), ("ResNet50", 1024), ("ResNet50", 1001), ("ResNet101", 128), ("ResNet152", 64),
+                                     ("ResNet101", 200), ("ResNet152", 176), ("ResNet152", 320)])
 def test_resident_stage_matches_tiled_kernels(eng, synth, model, n):
+    """512, 1024: two images a workgroup (one and two rounds of workgroups); 257, 301, 1001: an odd batch, the last
+    workgroup with one image; up to one image per CU: one image a workgroup; ResNet152 from 160 images on: a second
+    stage of eight blocks in the launch."""
     x = _images(n)
     tiled = _logits(eng, synth, model, x, resident=0)
     first = _logits(eng, synth, model, x, resident=1)
@@ -61,7 +65,7 @@ def test_resident_stage_matches_tiled_kernels(eng, synth, model, n):
 
 
 @pytest.mark.parametrize("dtype,bar", [("bf16", 0.6), ("f16", 0.08)])
-@pytest.mark.parametrize("n", [512, 37])
+@pytest.mark.parametrize("n", [512, 37, 200])
 def test_resident_stage_16bit(eng, synth, oracle, dtype, bar, n):
     """16-bit storage: both paths round every layer's result to the element type, from sums added in different
     orders, so they differ where a rounding falls the other way; each is held to the bar of the 16-bit
