@@ -203,6 +203,19 @@ int launch_resident_stage(const ResidentStage *s, hipStream_t stream, int n_imag
 // Whether a batch planned as n_images should take the second stage along.
 bool resident_stage_second(const ResidentStage *s, int n_images);
 
+// The reference's generator (Z -> 128 x 7 x 7 -> 64 x 14 x 14 -> 28 x 28) in one launch with its maps resident in LDS.
+struct ResidentGenerator;
+bool resident_generator_enabled();
+// w1t / sc1 / sh1: the first layer as gen_first_kernel takes it (device); w3: the second layer's torch weight (host);
+// l2: that layer (its device scale / shift are shared); w5: the last layer [16][64] (device).  *out stays null (and
+// GDPSO_OK is returned) when the device cannot run the kernel.
+int resident_generator_new(DeviceArena &arena, int dtype, int z_dim, const float *w1t, const float *sc1, const float *sh1, const float *w3,
+                           const ConvLayer *l2, const float *w5, float b5, ResidentGenerator **out);
+void resident_generator_free(ResidentGenerator *g);
+// z (latents, z_dim <= 16) or a1 (the first layer's output, elements of the network's type): one of them, the other null.
+int launch_resident_generator(const ResidentGenerator *g, hipStream_t stream, int n_images, int images_per_wg, const void *z, int z_is_f64,
+                              const void *a1, float *img, float *img01, const float *target, float *mse);
+
 // host-side helpers (pack.cpp)
 struct DeviceArena {
     std::vector<void *> blocks;

@@ -729,6 +729,10 @@ struct gdpso_generator {
     int num_cus;
     bool last_mfma;            // the last layer runs on the matrix cores (features % 16 == 0, <= 128)
     size_t last_mfma_lds_max;  // dynamic LDS the MFMA kernel may use on this device
+    // the whole generator as one launch with its maps in LDS (stage_resident.hip), or null: the reference's shape only
+    // (first kernel 7, 64 features: 28x28 images)
+    ResidentGenerator *resident = nullptr;
+    ~gdpso_generator() { resident_generator_free(resident); }
     DeviceArena arena;
 };
 
@@ -848,6 +852,10 @@ extern "C" int gdpso_generator_create_typed(gdpso_generator **out, int z_dim, in
             if (e2 == hipSuccess) g->last_mfma_lds_max = 152 * 1024;
         }
     }
+    if (first_kernel == 7 && features_g == 64 && resident_generator_enabled()) {
+        if ((rc = resident_generator_new(g->arena, dtype, z_dim, g->first_direct ? g->w1t : nullptr, g->l1.scale, g->l1.shift, t[6], &g->l2,
+                                         g->w5, g->b5, &g->resident))) { delete g; return rc; }
+    }
     *out = g;
     return GDPSO_OK;
 }
@@ -880,6 +888,18 @@ extern "C" int gdpso_generator_forward(const gdpso_generator *g, void *stream_, 
     float *sk = (float *)(ws + L.splitk);
     int rc;
     if ((rc = conv_splitk_prepare(stream, sk))) return rc;
+    // the whole generator in one launch with its maps in LDS, at the batch sizes the resident launches serve (the
+    // first layer too when the latents are short; else it stays a GEMM on the matrix cores and the launch reads its map)
+    const int resident_images = g->resident && resident_generator_enabled() ? resident_stage_images(plan_batch(n), g->num_cus) : 0;
+    if (resident_images > 0) {
+        if (g->first_direct)
+            return launch_resident_generator(g->resident, stream, n, resident_images, z, z_is_f64, nullptr, img, img01, target, mse);
+        const long ne = (long)n * g->kpad;
+        GDPSO_WITH_DTYPE(g->dtype, hipLaunchKernelGGL(latent_prep_kernel<E>, dim3(ceil_div(ne, 256)), dim3(256), 0, stream, z, z_is_f64, n,
+                                                      g->z_dim, g->kpad, (E *)zpad));
+        if ((rc = launch_conv(l1, stream, n, zpad, nullptr, a1, sk))) return rc;
+        return launch_resident_generator(g->resident, stream, n, resident_images, nullptr, 0, a1, img, img01, target, mse);
+    }
     if (g->first_direct) {
         const int ncol = g->k1 * g->k1 * 2 * g->features;
         GDPSO_WITH_DTYPE(g->dtype, hipLaunchKernelGGL(gen_first_kernel<E>, dim3(ceil_div(ncol / 4, 256), ceil_div(n, GF_IMAGES)), dim3(256), 0,

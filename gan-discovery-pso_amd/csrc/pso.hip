@@ -560,7 +560,8 @@ struct SwarmBatch {
     double w_cogn[MULTI_MAX], w_soci[MULTI_MAX], tolerance[MULTI_MAX];
     int schedule_inertia[MULTI_MAX], early_stopping[MULTI_MAX], f32_terms[MULTI_MAX];
     int dist_tile[MULTI_MAX], dist_tiles[MULTI_MAX];  // mean-distance tiling of each swarm
-    double *dist_partial[MULTI_MAX];
+    double *dist_partial[MULTI_MAX];  // this iteration's tile sums ...
+    double *dist_prev[MULTI_MAX];     // ... and, when the launch also finishes the previous iteration's mean, that one's (else null)
 };
 static_assert(sizeof(SwarmBatch) <= 3072, "kernel arguments are limited to 4 KiB");
 
@@ -719,12 +720,28 @@ __device__ __forceinline__ void pair_dist_tile_any(int ts, const double *__restr
 // workgroup q of part `part` takes tile part + q * n_parts -> partial[q].  One kernel per tile side: the
 // 64 x 64 tile's 16 running sums per thread cost it 176 registers (two workgroups per compute unit),
 // which the smaller tiles must not inherit.
+// A launch may carry one more workgroup behind its tiles (blockIdx.x == n_blocks) that finishes the PREVIOUS iteration's
+// mean from that iteration's tile sums (pair_dist_finish: the same additions in the same order as the finishing kernel).
+struct DistTail {
+    const double *partial;  // null: no such workgroup
+    int n_partial, iteration;
+    double pairs;
+    double *out;
+};
+
+__device__ __forceinline__ void pair_dist_finish(const double *__restrict__ partial, int n_partial, double pairs, double *__restrict__ out,
+                                                 double *s_sum);
+
 template <int TS>
 __global__ __launch_bounds__(256) void pair_dist_kernel(const double *__restrict__ pos, int n, int d, int blk_rows, size_t blk_stride,
                                                         int tiles, int part, int n_parts, const double *ctrl, int iteration,
-                                                        double *__restrict__ partial) {
+                                                        double *__restrict__ partial, int n_blocks, DistTail tail) {
     __shared__ __attribute__((aligned(16))) double sd[2 * TS * DIST_KCP];
     __shared__ double s_sum[4];
+    if ((int)blockIdx.x >= n_blocks) {
+        if (running(ctrl, tail.iteration)) pair_dist_finish(tail.partial, tail.n_partial, tail.pairs, tail.out, s_sum);
+        return;
+    }
     if (!running(ctrl, iteration)) return;
     pair_dist_tile<TS>(pos, n, d, blk_rows, blk_stride, tiles, part + (int)blockIdx.x * n_parts, partial + blockIdx.x, sd, s_sum);
 }
@@ -736,13 +753,20 @@ __global__ __launch_bounds__(256) void pair_dist_multi_kernel(SwarmBatch b, int 
     const int k = blockIdx.y;
     const gdpso_swarm &s = b.s[k];
     const int tiles = b.dist_tiles[k];
+    if (blockIdx.x + 1 == gridDim.x && b.dist_prev[k] != nullptr) {  // (a column of workgroups behind the tiles: the previous iteration's mean)
+        if (s.mean_dist && s.n >= 2 && running_multi(s, iteration - 1))
+            pair_dist_finish(b.dist_prev[k], tiles * (tiles + 1) / 2, 0.5 * (double)s.n * (double)(s.n - 1), s.mean_dist + (iteration - 2), s_sum);
+        return;
+    }
     if (!s.mean_dist || s.n < 2 || (int)blockIdx.x >= tiles * (tiles + 1) / 2 || !running_multi(s, iteration)) return;
     pair_dist_tile_any(b.dist_tile[k], s.pos, s.n, s.d, tiles, blockIdx.x, b.dist_partial[k] + blockIdx.x, sd, s_sum);
 }
 
-// The tile sums in a fixed order, in a launch of its own (folded into the tile kernel, with the
-// workgroup that finishes last adding up, it cost more than this launch: every workgroup then pays a
-// device-scope fence); pairs = 0: the sum itself (a rank's share) -> out, else the mean over `pairs` pairs.
+// The tile sums in a fixed order, behind the launch that made them (folded into the tile kernel, with the
+// workgroup that finishes last adding up, it cost more than a launch: every workgroup then pays a
+// device-scope fence): a launch of its own, or a workgroup of the NEXT iteration's tile launch (the fused loops:
+// the tile sums alternate between two buffers by the iteration's parity).
+// pairs = 0: the sum itself (a rank's share) -> out, else the mean over `pairs` pairs.
 __device__ __forceinline__ void pair_dist_finish(const double *__restrict__ partial, int n_partial, double pairs, double *__restrict__ out,
                                                  double *s_sum) {
     const int tid = threadIdx.x;
@@ -827,6 +851,13 @@ static size_t dist_tiles(int n, int dt) {
     const size_t t = (size_t)ceil_div(n, dt);
     return t * (t + 1) / 2;
 }
+// doubles between the two sets of tile sums of a swarm's scratch (set = iteration & 1 in the fused loops, else 0)
+static size_t dist_set_stride(size_t n_tiles) { return (n_tiles + 31) / 32 * 32; }
+
+static bool g_dist_defer = [] {
+    const char *e = getenv("GDPSO_DIST_DEFER");
+    return e ? e[0] != '0' : true;
+}();
 
 }  // namespace gdpso
 
@@ -835,8 +866,8 @@ using namespace gdpso;
 extern "C" size_t gdpso_swarm_scratch_bytes(int n) {
     if (n <= 0) return 0;
     const size_t partials = (size_t)ceil_div(n, PB) * sizeof(BestRec);
-    // distance partials sized for the smallest tile side
-    return (partials + 255) / 256 * 256 + dist_tiles(n, 16) * sizeof(double) + 256;
+    // distance partials sized for the smallest tile side, twice (the fused loops alternate between two sets)
+    return (partials + 255) / 256 * 256 + 2 * dist_set_stride(dist_tiles(n, 16)) * sizeof(double) + 256;
 }
 
 extern "C" int gdpso_swarm_reset(const gdpso_swarm *s, void *stream, double w_inertia) {
@@ -890,21 +921,32 @@ extern "C" int gdpso_swarm_move(const gdpso_swarm *s, void *stream, int iteratio
     return GDPSO_OK;
 }
 
-// tiles of part `part` of `n_parts` -> their sum in *out (pairs == 0) or the mean over `pairs` pairs
+// tiles of part `part` of `n_parts` -> their sum in *out (pairs == 0) or the mean over `pairs` pairs.
+// set: which of the scratch's two sets of tile sums; tiles / finish: which of the two steps to enqueue; tail_iteration
+// > 0 (with tiles): the tile launch carries a workgroup that finishes that iteration's mean from the OTHER set.
 static int launch_distance(const gdpso_swarm *s, void *stream, int iteration, const double *pos_all, int n_all, int part, int n_parts,
-                           double pairs, double *out, int blk_rows = 0, size_t blk_stride = 0) {
+                           double pairs, double *out, int blk_rows = 0, size_t blk_stride = 0, int set = 0, bool do_tiles = true,
+                           bool do_finish = true, int tail_iteration = 0) {
     if (blk_rows <= 0) blk_rows = n_all;  // positions back to back
     const int ts = dist_tile_side(n_all, n_parts);
     const int tiles = ceil_div(n_all, ts);
     const int nb_all = (int)dist_tiles(n_all, ts);
     const int nb = part < nb_all ? ceil_div(nb_all - part, n_parts) : 0;  // tiles part, part + n_parts, ...
-    double *partial = dist_partials(*s);
-    if (nb > 0) {
+    const size_t stride = dist_set_stride((size_t)nb_all);
+    double *partial = dist_partials(*s) + (size_t)set * stride;
+    if (do_tiles && (nb > 0 || tail_iteration > 0)) {
+        DistTail tail;
+        tail.partial = tail_iteration > 0 ? dist_partials(*s) + (size_t)(1 - set) * stride : nullptr;
+        tail.n_partial = nb;
+        tail.iteration = tail_iteration;
+        tail.pairs = pairs;
+        tail.out = tail_iteration > 0 ? s->mean_dist + (tail_iteration - 1) : nullptr;
         auto kernel = ts == 64 ? pair_dist_kernel<64> : ts == 32 ? pair_dist_kernel<32> : pair_dist_kernel<16>;
-        hipLaunchKernelGGL(kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, pos_all, n_all, s->d, blk_rows, blk_stride, tiles, part,
-                           n_parts, s->ctrl, iteration, partial);
+        hipLaunchKernelGGL(kernel, dim3(nb + (tail_iteration > 0 ? 1 : 0)), dim3(256), 0, (hipStream_t)stream, pos_all, n_all, s->d, blk_rows,
+                           blk_stride, tiles, part, n_parts, s->ctrl, iteration, partial, nb, tail);
     }
-    hipLaunchKernelGGL(pair_dist_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, nb, pairs, s->ctrl, iteration, out);
+    if (do_finish)
+        hipLaunchKernelGGL(pair_dist_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, nb, pairs, s->ctrl, iteration, out);
     GDPSO_HIP(hipGetLastError());
     return GDPSO_OK;
 }
@@ -989,6 +1031,9 @@ extern "C" int gdpso_swarm_iterate(const gdpso_swarm *s, const gdpso_generator *
                   "swarm_iterate: iteration range exceeds max_iter");
     GDPSO_REQUIRE(r->img01 && r->workspace, "swarm_iterate: null scratch buffer");
     GDPSO_REQUIRE(!r->target || (r->mse && r->img), "swarm_iterate: the inverter variant needs img and mse scratch");
+    const bool diag = r->diagnostics && s->mean_dist && s->n >= 2, defer = g_dist_defer;
+    const double pairs = 0.5 * (double)s->n * (double)(s->n - 1);
+    if (diag && n_iterations > 0 && (rc = check_distance(s, first_iteration, s->pos, s->n))) return rc;
     for (int i = first_iteration; i < first_iteration + n_iterations; ++i) {
         if ((rc = gdpso_generator_forward(g, stream, s->n, s->pos, 1, r->img, r->img01, r->target, r->target ? r->mse : nullptr,
                                           r->workspace, r->workspace_bytes)))
@@ -1017,8 +1062,14 @@ extern "C" int gdpso_swarm_iterate(const gdpso_swarm *s, const gdpso_generator *
             GDPSO_HIP(hipGetLastError());
             if ((rc = gdpso_swarm_move(s, stream, i, r->w_cogn, r->w_soci, rnd, r->seed, r->f32_first_move))) return rc;
         }
-        if (r->diagnostics && s->mean_dist && s->n >= 2)
-            if ((rc = gdpso_swarm_mean_distance(s, stream, i, s->pos, s->n))) return rc;
+        // the diagnostic: the tiles of iteration i now; their sums are added up by a workgroup of iteration i + 1's tile
+        // launch (one launch fewer per iteration), the last iteration's by the finishing kernel
+        if (diag) {
+            const bool last = i == first_iteration + n_iterations - 1;
+            if ((rc = launch_distance(s, stream, i, s->pos, s->n, 0, 1, pairs, s->mean_dist + (i - 1), 0, 0, defer ? (i & 1) : 0, true,
+                                      !defer || last, defer && i > first_iteration ? i - 1 : 0)))
+                return rc;
+        }
     }
     return GDPSO_OK;
 }
@@ -1050,6 +1101,7 @@ extern "C" int gdpso_swarm_iterate_multi(const gdpso_swarm *swarms, const gdpso_
     GDPSO_REQUIRE(r0.img01 && r0.workspace, "swarm_iterate_multi: runs[0] carries the shared image and workspace buffers");
     GDPSO_REQUIRE(n_swarms == 1 || class_per_image || gdpso_assessor_n_class(a) == 2,
                   "swarm_iterate_multi: a per-image class table is needed when the swarms are after different classes");
+    const bool defer = g_dist_defer;
     for (int i = first_iteration; i < first_iteration + n_iterations; ++i) {
         bool any = false;
         for (int k = 0; k < n_swarms; ++k) any |= i <= swarms[k].max_iter;
@@ -1087,7 +1139,9 @@ extern "C" int gdpso_swarm_iterate_multi(const gdpso_swarm *swarms, const gdpso_
                     const int DT = dist_tile_side(s.n, 1);
                     b.dist_tile[j] = DT;
                     b.dist_tiles[j] = ceil_div(s.n, DT);
-                    b.dist_partial[j] = dist_partials(s);
+                    const size_t set_stride = dist_set_stride(dist_tiles(s.n, DT));
+                    b.dist_partial[j] = dist_partials(s) + (defer ? (size_t)(i & 1) * set_stride : 0);
+                    b.dist_prev[j] = defer && i > first_iteration ? dist_partials(s) + (size_t)(1 - (i & 1)) * set_stride : nullptr;
                     max_blocks = std::max(max_blocks, (int)dist_tiles(s.n, DT));
                     max_ts = std::max(max_ts, DT);
                     dist = true;
@@ -1113,8 +1167,17 @@ extern "C" int gdpso_swarm_iterate_multi(const gdpso_swarm *swarms, const gdpso_
                 }
             }
             if (dist) {
-                hipLaunchKernelGGL(pair_dist_multi_kernel, dim3(max_blocks, cnt), dim3(256), dist_lds_bytes(max_ts), (hipStream_t)stream, b, i);
-                hipLaunchKernelGGL(pair_dist_finish_multi_kernel, dim3(cnt), dim3(256), 0, (hipStream_t)stream, b, i);
+                // (with the finish deferred: a last column of workgroups adds up the previous iteration's tile sums; the last
+                // iteration's are added up by the finishing kernel)
+                const bool tail = defer && i > first_iteration;
+                hipLaunchKernelGGL(pair_dist_multi_kernel, dim3(max_blocks + (tail ? 1 : 0), cnt), dim3(256), dist_lds_bytes(max_ts),
+                                   (hipStream_t)stream, b, i);
+                bool last = i == first_iteration + n_iterations - 1;
+                if (!last) {  // (or no swarm has an iteration i + 1)
+                    last = true;
+                    for (int k = 0; k < n_swarms; ++k) last = last && i + 1 > swarms[k].max_iter;
+                }
+                if (!defer || last) hipLaunchKernelGGL(pair_dist_finish_multi_kernel, dim3(cnt), dim3(256), 0, (hipStream_t)stream, b, i);
             }
             GDPSO_HIP(hipGetLastError());
         }

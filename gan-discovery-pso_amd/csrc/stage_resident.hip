@@ -38,6 +38,7 @@
 // tiled kernels round it on its way to memory.
 #include <hip/hip_ext.h>
 
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 
@@ -122,14 +123,20 @@ using global_f32x4 = const __attribute__((address_space(1))) f32x4;
 using global_f32 = const __attribute__((address_space(1))) float;
 
 // The matrix product of one layer for one wave: NRB row blocks (rb0, rb0 + RBSTEP, ...) x NCB column blocks
-// (cb0, cb0 + 1, ...) of 16 x 16 outputs, CIN input channels per tap, TAPS = 1 (1x1) or 9 (3x3, padding 1), input
+// (cb0, cb0 + 1, ...) of 16 x 16 outputs, CIN input channels per tap, TAPS = 1 (1x1), 9 (3x3, padding 1) or 4 (one
+// sub-pixel phase of a transposed convolution k4 s2 p1: the taps (0, 0), (0, sx), (sy, 0), (sy, sx), sy / sx = -1 for the
+// even output rows / columns of the phase, +1 for the odd ones), input
 // maps of S_IN x S_IN pixels, output maps of S_OUT x S_OUT, stride STRIDE; two images a workgroup, rows in
 // (image, y, x) order.  A: LDS rows of lda elements, row RS_ZERO_ROW all zeros when TAPS = 9 (taps outside the map
 // read it).  ROWS_OUT: the output rows that exist (lanes of rows past them repeat the last one; their sums are
 // dropped by the epilogue).  PF: k groups of B fragments in flight ahead of the one being multiplied.
-template <typename E, int NRB, int RBSTEP, int NCB, int CIN, int TAPS, int S_IN, int S_OUT, int STRIDE, int ROWS_OUT, int PF>
+// `rows` (the generator's second layer): the input row of every output row of the wave's blocks, for row blocks made of
+// rows of one border class (-1: a padding row); with GSKIP the last two row blocks hold the rows whose second tap
+// along y, resp. along x, leaves the map, and the k groups of those taps are left out for them.
+template <typename E, int NRB, int RBSTEP, int NCB, int CIN, int TAPS, int S_IN, int S_OUT, int STRIDE, int ROWS_OUT, int PF, bool GSKIP = false>
 __device__ __forceinline__ void rs_gemm(const E *__restrict__ A, const int lda, const void *w, const int rb0, const int cb0,
-                                        const int lane, f32x4 (&acc)[NRB][NCB]) {
+                                        const int lane, f32x4 (&acc)[NRB][NCB], const int sy = 0, const int sx = 0,
+                                        const short *__restrict__ rows = nullptr) {
     constexpr int VEC = RsLds<E>::VEC, KG = RsLds<E>::KG, GPT = CIN / KG, J = TAPS * GPT;
     constexpr bool PLAIN = TAPS == 1 && STRIDE == 1;  // output row r reads input row r
     const int lrow = lane & 15, lk = lane >> 4;
@@ -145,7 +152,11 @@ __device__ __forceinline__ void rs_gemm(const E *__restrict__ A, const int lda, 
     int arow[NRB], ay[NRB], ax[NRB];
 #pragma unroll
     for (int i = 0; i < NRB; ++i) {
-        const int row = ROWS_OUT % 16 == 0 ? (rb0 + i * RBSTEP) * 16 + lrow : min((rb0 + i * RBSTEP) * 16 + lrow, ROWS_OUT - 1);
+        int row = ROWS_OUT % 16 == 0 ? (rb0 + i * RBSTEP) * 16 + lrow : min((rb0 + i * RBSTEP) * 16 + lrow, ROWS_OUT - 1);
+        if (rows != nullptr) {
+            const int pr = rows[(rb0 + i * RBSTEP) * 16 + lrow];
+            row = pr < 0 ? ROWS_OUT - 1 : pr;
+        }
         if (PLAIN) {
             arow[i] = row;
             ay[i] = ax[i] = 0;
@@ -167,12 +178,23 @@ __device__ __forceinline__ void rs_gemm(const E *__restrict__ A, const int lda, 
             const bool ok = (unsigned)(ay[i] + dy) < (unsigned)S_IN && (unsigned)(ax[i] + dx) < (unsigned)S_IN;
             row = ok ? row + dy * S_IN + dx : RS_ZERO_ROW;
         }
+        if (TAPS == 4) {
+            const int dy = (tap >> 1) ? sy : 0, dx = (tap & 1) ? sx : 0;
+            const bool ok = (unsigned)(ay[i] + dy) < (unsigned)S_IN && (unsigned)(ax[i] + dx) < (unsigned)S_IN;
+            row = ok ? row + dy * S_IN + dx : RS_ZERO_ROW;
+        }
         return *(const f32x4 *)(A + row * lda + c0 + VEC * lk);
     };
 #pragma unroll
     for (int i = 0; i < NRB; ++i)
 #pragma unroll
         for (int c = 0; c < NCB; ++c) acc[i][c] = 0.f;
+    // (GSKIP) whether row block i takes part in k group j
+    auto live = [&](int i, int j) -> bool {
+        if (!GSKIP) return true;
+        const int tap = j / GPT;
+        return !((i == NRB - 2 && (tap >> 1) == 1) || (i == NRB - 1 && (tap & 1) == 1));
+    };
     f32x4 aq[2][NRB];
 #pragma unroll
     for (int i = 0; i < NRB; ++i) aq[0][i] = a_load(i, 0);
@@ -183,7 +205,8 @@ __device__ __forceinline__ void rs_gemm(const E *__restrict__ A, const int lda, 
         __builtin_amdgcn_sched_barrier(0);
         if (j + 1 < J) {
 #pragma unroll
-            for (int i = 0; i < NRB; ++i) aq[(j + 1) & 1][i] = a_load(i, j + 1);
+            for (int i = 0; i < NRB; ++i)
+                if (live(i, j + 1)) aq[(j + 1) & 1][i] = a_load(i, j + 1);
         }
         f32x4 bcur[NCB];
 #pragma unroll
@@ -197,14 +220,18 @@ __device__ __forceinline__ void rs_gemm(const E *__restrict__ A, const int lda, 
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int i = 0; i < NRB; ++i)
+                    if (live(i, j)) {
 #pragma unroll
-                    for (int c = 0; c < NCB; ++c)
-                        acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[j & 1][i][s], bcur[c][s], acc[i][c], 0, 0, 0);
+                        for (int c = 0; c < NCB; ++c)
+                            acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[j & 1][i][s], bcur[c][s], acc[i][c], 0, 0, 0);
+                    }
         } else {
 #pragma unroll
             for (int i = 0; i < NRB; ++i)
+                if (live(i, j)) {
 #pragma unroll
-                for (int c = 0; c < NCB; ++c) acc[i][c] = rs_mfma<E>(aq[j & 1][i], bcur[c], acc[i][c]);
+                    for (int c = 0; c < NCB; ++c) acc[i][c] = rs_mfma<E>(aq[j & 1][i], bcur[c], acc[i][c]);
+                }
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -490,17 +517,248 @@ __global__ __launch_bounds__(512) void stage_resident_kernel(const RsArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------ the generator
+// The reference's generator (src/utils/util_dcgan.py:128-149: ConvTranspose2d(Z -> 128, k7) + BN + ReLU,
+// ConvTranspose2d(128 -> 64, k4, s2, p1) + BN + ReLU, ConvTranspose2d(64 -> 1, k4, s2, p1) + tanh) and the per-image
+// rescale (src/utils/util_data.py:129-135) the same way: a workgroup takes two images (or one), keeps the 7x7x128 map of
+// the first layer (98 rows) and the 14x14x64 map of the second (392 rows) in LDS and writes only the images.  The
+// second layer is four sub-pixel phases, each a 2x2-tap convolution of 98 rows x 64 columns with K = 512: wave w takes
+// phase w >> 1 and column blocks 2 (w & 1), 2 (w & 1) + 1 with all seven row blocks, through rs_gemm (the A operand in LDS,
+// weights from global memory in fragment order); its epilogue scatters a row to pixel (2 my + py, 2 mx + px) of the
+// 14x14 map.  The first layer (latents of up to 16 dimensions) is the arithmetic of gen_first_kernel, the last layer,
+// tanh, min / max and rescale that of gen_last_mfma_kernel (nets.hip; same operand order, same bits given the same
+// 14x14 map); longer latents leave the first layer to the matrix-core GEMM and the kernel reads its output.
+constexpr int GR_C1 = 128, GR_C2 = 64, GR_HIN = 14, GR_NIN = GR_HIN * GR_HIN, GR_SIDE = 28, GR_NPIX = GR_SIDE * GR_SIDE;
+constexpr int GR_NCOL = RS_PIX * GR_C1, GR_MAX_Z = 16, GR_NBLK = (GR_NIN + 15) / 16;
+
+template <typename E>
+struct GrLds {
+    static constexpr int VEC = 16 / (int)sizeof(E);
+    static constexpr int LDA1 = GR_C1 + VEC, LDA2 = GR_C2 + VEC;
+    static constexpr size_t A1_BYTES = (size_t)(RS_ROWS + 1) * LDA1 * sizeof(E), A2_OFF = A1_BYTES;
+    static constexpr size_t A2_BYTES = (size_t)RS_IMAGES * GR_NIN * LDA2 * sizeof(E), ROWS_OFF = A2_OFF + A2_BYTES;
+    static constexpr size_t BYTES = ROWS_OFF + 4 * 112 * sizeof(short);  // (behind the maps: the phases' row orders, see GrArgs::rows)
+    // the last layer's products [2 x 208][16] floats, one image [784] floats and the reduction slots lie where the first
+    // map was (and, with 16-bit storage, run on into the second map, which is dead by the time they are written)
+    static constexpr size_t SC_OFF = 0, SC_BYTES = (size_t)RS_IMAGES * GR_NBLK * 16 * 16 * 4, SIMG_OFF = SC_BYTES, SRED_OFF = SIMG_OFF + GR_NPIX * 4;
+    static_assert(SC_BYTES <= A2_OFF && SRED_OFF + 128 <= ROWS_OFF && BYTES <= 160 * 1024, "LDS layout");
+};
+
+struct GrArgs {
+    const void *z;            // latents [n][zd], float64 or float32 (zd <= GR_MAX_Z), or null:
+    const void *a1;           // ... the first layer's output [n][49][128], elements of the network's type
+    int z_is_f64, zd, n;
+    const float *w1t, *sc1, *sh1;  // first layer: [zd][6272] (column = pixel * 128 + channel), scale / shift [6272]
+    const void *w3;                // second layer in fragment order: [4 phases][4 column blocks][512 / KG][64 lanes][VEC]
+    const float *sc3, *sh3;        // [64]
+    const short *rows;             // [4 phases][112]: the rows of a phase ordered by border class (two images a workgroup), -1 = padding
+    const float *w5;               // last layer [16 kernel positions][64]
+    float b5;
+    float *img, *img01;            // [n][28][28]: tanh output (may be null), rescaled image
+    const float *target;           // inverter variant: target images and the pixel MSE against them, or null
+    float *mse;
+};
+
+template <typename E, int IMG>
+__global__ __launch_bounds__(512) void gen_resident_kernel(const GrArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using LY = GrLds<E>;
+    constexpr int VEC = LY::VEC, LDA1 = LY::LDA1, LDA2 = LY::LDA2, ROWS = IMG * RS_PIX, NRB = (ROWS + 15) / 16;
+    E *A1 = (E *)smem, *A2 = (E *)(smem + LY::A2_OFF);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 15, lk = lane >> 4;
+    const int img0 = blockIdx.x * IMG, nimg = min(IMG, a.n - img0);
+    if (tid < LDA1 * (int)sizeof(E) / 16) *(f32x4 *)((char *)(A1 + RS_ZERO_ROW * LDA1) + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    short *s_rows = (short *)(smem + LY::ROWS_OFF);
+    if (IMG == 2 && tid < 4 * 112) s_rows[tid] = a.rows[tid];
+    // ---- first layer
+    if (a.z != nullptr) {
+        float *s_z = (float *)A2;  // [IMG][GR_MAX_Z]
+        if (tid < IMG * GR_MAX_Z) {
+            const int i = tid / GR_MAX_Z, k = tid % GR_MAX_Z, im = img0 + i;
+            float v = 0.f;
+            if (i < nimg && k < a.zd) v = a.z_is_f64 ? (float)((const double *)a.z)[(long)im * a.zd + k] : ((const float *)a.z)[(long)im * a.zd + k];
+            s_z[tid] = (float)(E)v;  // (16-bit storage: the latent rounded as the matrix-core path rounds its A operand)
+        }
+        __syncthreads();
+        for (int q = tid; q < GR_NCOL / 4; q += 512) {
+            const int col = q * 4;
+            f32x4 w[GR_MAX_Z];
+#pragma unroll
+            for (int k = 0; k < GR_MAX_Z; ++k) {
+                w[k] = 0.f;
+                if (k < a.zd) w[k] = *(global_f32x4 *)(a.w1t + (size_t)k * GR_NCOL + col);
+            }
+            const f32x4 sc = *(global_f32x4 *)(a.sc1 + col), sh = *(global_f32x4 *)(a.sh1 + col);
+#pragma unroll
+            for (int i = 0; i < IMG; ++i) {
+                f32x4 acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < GR_MAX_Z; ++j) {
+                    const int g = j >> 3, h = j & 1, st = (j >> 1) & 3, k = 8 * g + 4 * h + st;  // 0, 4, 1, 5, 2, 6, 3, 7, 8, 12, ...
+                    if (k < a.zd) {
+                        const float zk = s_z[i * GR_MAX_Z + k];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) acc[c] = fmaf(zk, w[k][c], acc[c]);
+                    }
+                }
+                f32x4 v = acc * sc + sh;
+                E *o = A1 + (i * RS_PIX + col / GR_C1) * LDA1 + col % GR_C1;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c] = (E)fmaxf(v[c], 0.f);
+            }
+        }
+    } else {
+        constexpr int QPR = GR_C1 / VEC;  // 16-byte words per row
+        global_f32x4 *src = (global_f32x4 *)((const E *)a.a1 + (size_t)img0 * RS_PIX * GR_C1);
+        for (int i = tid; i < ROWS * QPR; i += 512) {
+            const int r = i / QPR, c = (i - r * QPR) * VEC;
+            f32x4 v = 0.f;
+            if (r < nimg * RS_PIX) v = src[i];
+            *(f32x4 *)(A1 + r * LDA1 + c) = v;
+        }
+    }
+    __syncthreads();
+    // ---- second layer: four phases of 98 rows x 64 columns x K = 512
+    {
+        constexpr int J3 = 4 * GR_C1 / RsLds<E>::KG;
+        const int ph = wave >> 1, py = ph >> 1, px = ph & 1, cb0 = 2 * (wave & 1);
+        float sc[2], sh[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            sc[c] = ((global_f32 *)a.sc3)[(cb0 + c) * 16 + lrow];
+            sh[c] = ((global_f32 *)a.sh3)[(cb0 + c) * 16 + lrow];
+        }
+        f32x4 acc[NRB][2];
+        // two images: the rows of a phase in border classes (a.rows: interior rows in five blocks, then the rows whose
+        // second tap along y leaves the map, then those whose second tap along x does), so that the last two blocks skip
+        // those taps: 24 tap-blocks instead of 28.  One image has too few rows for that (4 blocks either way).
+        const short *rows = IMG == 2 ? s_rows + ph * 16 * NRB : nullptr;
+        rs_gemm<E, NRB, 1, 2, GR_C1, 4, RS_SIDE, RS_SIDE, 1, ROWS, 3, IMG == 2>(A1, LDA1, (const f32x4 *)a.w3 + (size_t)ph * 4 * J3 * 64, 0, cb0,
+                                                                               lane, acc, py ? 1 : -1, px ? 1 : -1, rows);
+#pragma unroll
+        for (int i = 0; i < NRB; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rows != nullptr ? rows[i * 16 + 4 * lk + r] : i * 16 + 4 * lk + r;
+                if (row >= 0 && row < ROWS) {
+                    const int im = row >= RS_PIX ? 1 : 0, p = row - im * RS_PIX, my = (p * 37) >> 8, mx = p - my * RS_SIDE;
+                    E *o = A2 + (im * GR_NIN + (2 * my + py) * GR_HIN + 2 * mx + px) * LDA2 + cb0 * 16 + lrow;
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) o[c * 16] = (E)fmaxf(acc[i][c][r] * sc[c] + sh[c], 0.f);
+                }
+            }
+    }
+    __syncthreads();
+    // ---- last layer: C[input pixel][kernel position] = A2[pixel][channel] * W5[channel][position] per image
+    float *s_c = (float *)(smem + LY::SC_OFF), *s_img = (float *)(smem + LY::SIMG_OFF), *s_red = (float *)(smem + LY::SRED_OFF);
+    {
+        f32x4 bfrag[GR_C2 / 16];
+#pragma unroll
+        for (int j = 0; j < GR_C2 / 16; ++j) bfrag[j] = *(global_f32x4 *)&a.w5[(size_t)lrow * GR_C2 + 16 * j + 4 * lk];
+        f32x4 accs[(IMG * GR_NBLK + 7) / 8];
+#pragma unroll
+        for (int t = 0; t < (IMG * GR_NBLK + 7) / 8; ++t) {
+            const int b = wave + 8 * t;
+            accs[t] = 0.f;
+            if (b < IMG * GR_NBLK) {
+                const int im = b >= GR_NBLK ? 1 : 0, bb = b - im * GR_NBLK;
+                const E *pa = A2 + (im * GR_NIN + min(bb * 16 + lrow, GR_NIN - 1)) * LDA2 + 4 * lk;
+#pragma unroll
+                for (int j = 0; j < GR_C2 / 16; ++j) {
+                    f32x4 av;
+                    if constexpr (is_f32<E>()) {
+                        av = *(const f32x4 *)(pa + 16 * j);
+                    } else {
+                        using V = __attribute__((ext_vector_type(4))) E;
+                        const V v = *(const V *)(pa + 16 * j);
+                        av = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+                    }
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) accs[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bfrag[j][s], accs[t], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();  // every wave has read the second map: the products may overwrite the first map's place (and beyond)
+#pragma unroll
+        for (int t = 0; t < (IMG * GR_NBLK + 7) / 8; ++t) {
+            const int b = wave + 8 * t;
+            if (b < IMG * GR_NBLK) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s_c[(b * 16 + 4 * lk + r) * 16 + lrow] = accs[t][r];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- per image: gather the four contributions of every output pixel, bias + tanh, min / max, rescale
+    for (int im = 0; im < nimg; ++im) {
+        const int n = img0 + im;
+        const float *sc_im = s_c + im * GR_NBLK * 16 * 16;
+        float mn = INFINITY, mx = -INFINITY, se = 0.f;
+        float *dst = a.img ? a.img + (size_t)n * GR_NPIX : nullptr;
+        const float *tg = a.target ? a.target + (size_t)n * GR_NPIX : nullptr;
+        for (int i = tid; i < GR_NPIX; i += 512) {
+            const int oy = i / GR_SIDE, ox = i - oy * GR_SIDE;
+            const int py = oy & 1, my = oy >> 1, px = ox & 1, mxx = ox >> 1;
+            // (input offset, kernel index) = (0, 1), (-1, 3) for even rows; (0, 2), (+1, 0) for odd; same along x
+            const int iy1 = my + (py ? 1 : -1), ky0 = py ? 2 : 1, ky1 = py ? 0 : 3;
+            const int ix1 = mxx + (px ? 1 : -1), kx0 = px ? 2 : 1, kx1 = px ? 0 : 3;
+            const bool yok = (unsigned)iy1 < (unsigned)GR_HIN, xok = (unsigned)ix1 < (unsigned)GR_HIN;
+            const float t00 = sc_im[(my * GR_HIN + mxx) * 16 + ky0 * 4 + kx0];
+            const float t01 = xok ? sc_im[(my * GR_HIN + ix1) * 16 + ky0 * 4 + kx1] : 0.f;
+            const float t10 = yok ? sc_im[(iy1 * GR_HIN + mxx) * 16 + ky1 * 4 + kx0] : 0.f;
+            const float t11 = (yok && xok) ? sc_im[(iy1 * GR_HIN + ix1) * 16 + ky1 * 4 + kx1] : 0.f;
+            const float v = tanhf(((t00 + t01) + (t10 + t11)) + a.b5);
+            s_img[i] = v;
+            mn = fminf(mn, v);
+            mx = fmaxf(mx, v);
+            if (dst) dst[i] = v;
+            if (tg) {
+                const float dlt = tg[i] - v;
+                se = fmaf(dlt, dlt, se);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn = fminf(mn, __shfl_xor(mn, o));
+            mx = fmaxf(mx, __shfl_xor(mx, o));
+            se += __shfl_xor(se, o);
+        }
+        if (lane == 0) {
+            s_red[wave] = mn;
+            s_red[8 + wave] = mx;
+            s_red[16 + wave] = se;
+        }
+        __syncthreads();
+        mn = s_red[0];
+        mx = s_red[8];
+        se = s_red[16];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) {
+            mn = fminf(mn, s_red[k]);
+            mx = fmaxf(mx, s_red[8 + k]);
+            se += s_red[16 + k];
+        }
+        const float range = mx - mn;
+        float *d01 = a.img01 + (size_t)n * GR_NPIX;
+        for (int i = tid; i < GR_NPIX; i += 512) d01[i] = (s_img[i] - mn) / range;  // each thread rescales the pixels it wrote
+        if (a.mse && tid == 0) a.mse[n] = se / (float)GR_NPIX;
+        __syncthreads();  // the next image reuses s_img / s_red
+    }
+}
+
 // ------------------------------------------------------------------------------------ host side
 static bool g_rs_enabled = [] {
     const char *e = getenv("GDPSO_STAGE1_RESIDENT");
     return e ? e[0] != '0' : true;
 }();
-// Largest batch (as planned: plan_batch) that takes the resident kernel.  Its workgroups are one per CU
-// and run for the whole stage, so batches of several rounds are better served by the tiled kernels,
-// whose large grids reach a higher fraction of the matrix peak.
+// Largest batch (as planned: plan_batch) that takes the resident kernel: none by default.  Its workgroups are one
+// per CU and run for the whole stage, so a large batch is served in rounds; measured against the tiled kernels (whose
+// large grids reach a higher fraction of the matrix peak, but in some fifty launches with every map through memory)
+// the resident launches still come out ahead at whole rounds: +7 % at 2048 particles, +2 % at 4096 ... 16384.
+constexpr int RS_NO_LIMIT = 1 << 30;
 static int g_rs_max_images = [] {
     const char *e = getenv("GDPSO_STAGE1_RESIDENT_MAX");
-    return e ? atoi(e) : 1024;
+    return e ? atoi(e) : RS_NO_LIMIT;
 }();
 // Smallest batch that takes it: below, a handful of workgroups walk some sixty layers on a few CUs while the tiled
 // kernels spread every layer over the device.
@@ -635,7 +893,7 @@ int resident_stage_new(DeviceArena &arena, int dtype, int nblocks, const float *
 // layers, so the launch takes rounds x (time of one workgroup): one image a workgroup while that still leaves every
 // image a CU of its own, two up to two images per CU; beyond, whole rounds of 2 x num_cus images, worth it only
 // when the last round is nearly full (measured on MI355X, 256 CUs, fp32: 64 ... 256 images one a workgroup, ... 512
-// two; 768 images = 1.5 rounds lose to the tiled kernels, 1024 = 2 rounds win).
+// two; 768 images = 1.5 rounds lose to the tiled kernels, 1280 = 2.5 rounds come out even, whole rounds win).
 int resident_stage_images(int n_images, int num_cus) {
     if (n_images < g_rs_min_images || n_images > g_rs_max_images) return 0;
     if (g_rs_force_images > 0) return g_rs_force_images;
@@ -694,6 +952,138 @@ int launch_resident_stage(const ResidentStage *s, hipStream_t stream, int n_imag
     return GDPSO_OK;
 }
 
+// ---- the resident generator (host side)
+static bool g_gr_enabled = [] {
+    const char *e = getenv("GDPSO_GEN_RESIDENT");
+    return e ? e[0] != '0' : true;
+}();
+
+struct ResidentGenerator {
+    int dtype;
+    GrArgs args;  // weights filled in; latents / first map, outputs and n per launch
+    double flops, executed2, executed1, weight_bytes;  // second layer, per image: nominal, multiplied with two / one image a workgroup
+};
+
+bool resident_generator_enabled() { return g_gr_enabled; }
+void resident_generator_free(ResidentGenerator *g) { delete g; }
+
+// w3: the second layer's torch weight [128][64][4][4] (ConvTranspose2d layout [cin][cout][ky][kx]).
+int resident_generator_new(DeviceArena &arena, int dtype, int z_dim, const float *w1t, const float *sc1, const float *sh1, const float *w3,
+                           const ConvLayer *l2, const float *w5, float b5, ResidentGenerator **out) {
+    *out = nullptr;
+    hipError_t e = hipSuccess;
+#define GDPSO_GR_ATTR(IMG)                                                                                                    \
+    if (e == hipSuccess)                                                                                                      \
+        GDPSO_WITH_DTYPE(dtype, e = hipFuncSetAttribute((const void *)gen_resident_kernel<E, IMG>,                             \
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)GrLds<E>::BYTES));
+    GDPSO_GR_ATTR(1) GDPSO_GR_ATTR(2)
+#undef GDPSO_GR_ATTR
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return GDPSO_OK;  // (not an error: the tiled kernels remain)
+    }
+    auto g = new ResidentGenerator();
+    std::memset(&g->args, 0, sizeof(g->args));
+    g->dtype = dtype;
+    g->args.zd = z_dim;
+    g->args.w1t = w1t;
+    g->args.sc1 = sc1;
+    g->args.sh1 = sh1;
+    g->args.sc3 = l2->scale;
+    g->args.sh3 = l2->shift;
+    g->args.w5 = w5;
+    g->args.b5 = b5;
+    // fragment order per phase: B[k = tap * 128 + ci][co] = W[ci][co][ky][kx], tap = 2 ty + tx, ky = 1 | 3 (even output
+    // rows: offsets 0 | -1) or 2 | 0 (odd rows: 0 | +1), the same along x
+    const int es = (int)dtype_size(dtype), vec = 16 / es, kg = dtype == DT_F32 ? 16 : 32, K = 4 * GR_C1, J = K / kg;
+    std::vector<uint8_t> packed((size_t)4 * GR_C2 * K * es);
+    for (int ph = 0; ph < 4; ++ph) {
+        const int py = ph >> 1, px = ph & 1;
+        for (int cb = 0; cb < GR_C2 / 16; ++cb)
+            for (int j = 0; j < J; ++j)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int s = 0; s < vec; ++s) {
+                        const int co = cb * 16 + (lane & 15), k = kg * j + vec * (lane >> 4) + s;
+                        const int tap = k / GR_C1, ci = k - tap * GR_C1, ty = tap >> 1, tx = tap & 1;
+                        const int ky = ty == 0 ? (py ? 2 : 1) : (py ? 0 : 3), kx = tx == 0 ? (px ? 2 : 1) : (px ? 0 : 3);
+                        const float v = w3[(((size_t)ci * GR_C2 + co) * 4 + ky) * 4 + kx];
+                        const size_t at = ((((size_t)ph * (GR_C2 / 16) + cb) * J + j) * 64 + lane) * vec + s;
+                        if (dtype == DT_F32) {
+                            std::memcpy(&packed[at * 4], &v, 4);
+                        } else {
+                            const uint16_t h = dtype == DT_BF16 ? f32_to_bf16_bits(v) : f32_to_f16_bits(v);
+                            std::memcpy(&packed[at * 2], &h, 2);
+                        }
+                    }
+    }
+    int rc = arena.upload(packed.data(), packed.size(), &g->args.w3);
+    // rows of a phase by border class: a phase's second tap along y reads row my + 1 (odd output rows) or my - 1 (even),
+    // so it leaves the map for my = 6 resp. 0; the same along x
+    std::vector<int16_t> rows(4 * 112, -1);
+    for (int ph = 0; ph < 4; ++ph) {
+        const int ybord = (ph >> 1) ? RS_SIDE - 1 : 0, xbord = (ph & 1) ? RS_SIDE - 1 : 0;
+        int16_t *t = rows.data() + ph * 112;
+        int n0 = 0, ny = 80, nx = 96;  // interior rows from 0 (72 of them), y-border rows from 80 (14), x-border rows from 96 (12)
+        for (int r = 0; r < RS_ROWS; ++r) {
+            const int p = r % RS_PIX, my = p / RS_SIDE, mx = p % RS_SIDE;
+            if (my == ybord)
+                t[ny++] = (int16_t)r;  // (a corner row's x tap reads the row of zeros)
+            else if (mx == xbord)
+                t[nx++] = (int16_t)r;
+            else
+                t[n0++] = (int16_t)r;
+        }
+    }
+    if (!rc) rc = arena.upload(rows.data(), rows.size() * sizeof(int16_t), (const void **)&g->args.rows);
+    if (rc) {
+        delete g;
+        return rc;
+    }
+    g->flops = l2->flops_nominal;
+    g->executed2 = 2.0 * 4 * 16 * (5 + 0.5 + 0.5) / 2 * GR_C2 * K;  // 5 row blocks with four taps, 2 with two
+    g->executed1 = 2.0 * 4 * 64 * GR_C2 * K;
+    g->weight_bytes = (double)es * 4 * GR_C2 * K;
+    *out = g;
+    return GDPSO_OK;
+}
+
+// z (latents, z_dim <= 16 only) or a1 (the first layer's output) is given, the other null.
+int launch_resident_generator(const ResidentGenerator *g, hipStream_t stream, int n_images, int images_per_wg, const void *z, int z_is_f64,
+                              const void *a1, float *img, float *img01, const float *target, float *mse) {
+    if (images_per_wg != 1 && images_per_wg != 2) return fail(GDPSO_ERR_ARG, "resident generator: one or two images a workgroup");
+    if ((z == nullptr) == (a1 == nullptr)) return fail(GDPSO_ERR_ARG, "resident generator: latents or the first map, not both");
+    if (z != nullptr && g->args.zd > GR_MAX_Z) return fail(GDPSO_ERR_ARG, "resident generator: latents of more than 16 dimensions");
+    GrArgs a = g->args;
+    a.z = z;
+    a.z_is_f64 = z_is_f64;
+    a.a1 = a1;
+    a.n = n_images;
+    a.img = img;
+    a.img01 = img01;
+    a.target = target;
+    a.mse = mse;
+    const dim3 grid((unsigned)ceil_div(n_images, images_per_wg));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool timed = conv_timing_slot(&e0, &e1);
+    if (timed)
+        conv_timing_account(g->flops * n_images, (images_per_wg == 2 ? g->executed2 : g->executed1) * n_images,
+                            g->weight_bytes + (double)n_images * (dtype_size(g->dtype) * (a1 ? (double)RS_PIX * GR_C1 : 0.0) + 8.0 * GR_NPIX));
+#define GDPSO_GR_LAUNCH(IMG)                                                                                                          \
+    if (timed) {                                                                                                                      \
+        GDPSO_WITH_DTYPE(g->dtype, hipExtLaunchKernelGGL((gen_resident_kernel<E, IMG>), grid, dim3(512), GrLds<E>::BYTES, stream, e0, e1, 0, a)); \
+    } else {                                                                                                                          \
+        GDPSO_WITH_DTYPE(g->dtype, hipLaunchKernelGGL((gen_resident_kernel<E, IMG>), grid, dim3(512), GrLds<E>::BYTES, stream, a));    \
+    }
+    if (images_per_wg == 2) {
+        GDPSO_GR_LAUNCH(2)
+    } else {
+        GDPSO_GR_LAUNCH(1)
+    }
+#undef GDPSO_GR_LAUNCH
+    GDPSO_HIP(hipGetLastError());
+    return GDPSO_OK;
+}
+
 }  // namespace gdpso
 
 extern "C" int gdpso_resident_options(int stages, int max_images, int min_images) {
@@ -704,6 +1094,11 @@ extern "C" int gdpso_resident_options(int stages, int max_images, int min_images
     g_rs_enabled = stages != 0;
     g_rs_stage2 = stages == 2;
     if (max_images > 0) g_rs_max_images = max_images;
+    return GDPSO_OK;
+}
+
+extern "C" int gdpso_resident_generator_option(int enabled) {
+    gdpso::g_gr_enabled = enabled != 0;
     return GDPSO_OK;
 }
 

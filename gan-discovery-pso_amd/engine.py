@@ -150,8 +150,14 @@ def resident_options(stages: int = 2, max_images: int = 0, min_images: int = 0) 
     ``stages`` 0: stem and every ResNet stage through the tiled convolution kernels; 1: stem and first stage
     in one launch with their maps in LDS; 2 (default): the second stage too.  ``max_images`` / ``min_images``
     > 0: largest / smallest planned batch that takes the resident kernel (0: keep the current limit; defaults
-    1024 and 64).  The paths agree to fp32 rounding, not bit for bit."""
+    none and 64).  The paths agree to fp32 rounding, not bit for bit."""
     check(_lib.lib().gdpso_resident_options(int(stages), int(max_images), int(min_images)))
+
+
+def resident_generator(enabled: bool = True) -> None:
+    """The generator of the reference's shape as one launch with its maps in LDS (gdpso_resident_generator_option),
+    at the batch sizes of the resident launches; False: the tiled kernels.  From the next forward call."""
+    check(_lib.lib().gdpso_resident_generator_option(int(bool(enabled))))
 
 
 class _Handle:

@@ -413,14 +413,24 @@ int gdpso_plan_options(int plan_images, int splitk);
  * created and launch plans made from now on.  stages = 0: stem and every stage run through the tiled kernels
  * (A/B runs and tests); 1: the stem and the first stage are resident; 2 (default): the second stage as well.
  * max_images / min_images > 0: the largest / smallest (planned, see gdpso_plan_options) batch that takes the
- * resident kernel; 0 keeps the current limit (defaults 1024 and 64: larger batches fill the device better with
- * the tiled kernels, smaller ones leave most CUs without a workgroup; in between a workgroup takes one image up to
- * one image per CU, two beyond, and batches of more than two images per CU only when whole rounds of workgroups
- * come out nearly full).  The paths
+ * resident kernel; 0 keeps the current limit (defaults: no upper limit, 64 below: smaller batches leave most CUs
+ * without a workgroup; a workgroup takes one image up to one image per CU, two beyond, and batches of more than
+ * two images per CU take the launch only when its rounds of workgroups come out at least 85 % full: 768 images on
+ * 256 CUs go to the tiled kernels, 1024 or 4096 to the resident launch).  The paths
  * add a row's products in different orders and agree to fp32 rounding (to the element type's rounding for 16-bit
  * storage).  Environment: GDPSO_STAGE1_RESIDENT (0: none), GDPSO_STAGE2_RESIDENT (0: first stage only),
  * GDPSO_STAGE1_RESIDENT_MAX, GDPSO_STAGE1_RESIDENT_MIN give the initial values. */
 int gdpso_resident_options(int stages, int max_images, int min_images);
+
+/* No counterpart in the reference (its generator is three torch modules, src/utils/util_dcgan.py:128-149): at
+ * the batch sizes gdpso_resident_options gives the resident launches, a generator of the reference's shape
+ * (28x28 images, 64 features, first kernel 7) runs as ONE launch: a workgroup takes one or two latents, keeps
+ * the 7x7x128 and 14x14x64 maps in LDS, streams the second layer's weights per output phase and writes the image
+ * (and its [0,1] copy, and the inverter's mean squared error).  Latents of more than 16 dimensions keep their first
+ * layer as a GEMM launch in front.  enabled = 0: the tiled kernels at every batch size.  Takes effect from the next
+ * forward call.  First and last layer add in the tiled kernels' order; the second layer's sums are ordered
+ * differently (fp32 rounding apart).  Environment: GDPSO_GEN_RESIDENT (0: off) gives the initial value. */
+int gdpso_resident_generator_option(int enabled);
 
 /* No counterpart in the reference: a test aid.  Launch plans made from now on give every workgroup of the
  * resident launch this many images (1 or 2) whatever the batch size (within the limits of

@@ -13,7 +13,7 @@ import os
 pytestmark = pytest.mark.gpu
 # what the process started with (tools/switch_matrix.sh runs the suite under the environment switches): restored after every case
 ENV_STAGES = 0 if os.environ.get("GDPSO_STAGE1_RESIDENT", "1") == "0" else 1 if os.environ.get("GDPSO_STAGE2_RESIDENT", "1") == "0" else 2
-ENV_MAX = int(os.environ.get("GDPSO_STAGE1_RESIDENT_MAX", "1024"))
+ENV_MAX = int(os.environ.get("GDPSO_STAGE1_RESIDENT_MAX", str(1 << 30)))
 ENV_MIN = int(os.environ.get("GDPSO_STAGE1_RESIDENT_MIN", "64"))
 # (the second stage's own lower limit is an environment switch only)
 S2_MIN = int(os.environ.get("GDPSO_STAGE2_RESIDENT_MIN", "160"))
@@ -24,7 +24,7 @@ def eng():
     return importlib.import_module("gan-discovery-pso_amd.engine")
 
 
-def _logits(eng, synth, model, x, resident, max_images=1024, n_class=8, dtype="f32", min_images=1):
+def _logits(eng, synth, model, x, resident, max_images=1 << 30, n_class=8, dtype="f32", min_images=1):
     dev = torch.device("cuda:0")
     eng.resident_options(int(resident), max_images, min_images)
     try:
@@ -46,10 +46,10 @@ def _images(n, seed=5):
 
 
 @pytest.mark.parametrize("model,n", [("ResNet50", 512), ("ResNet50", 1), ("ResNet50", 2), ("ResNet50", 37), ("ResNet50", 301),
-                                     ("ResNet50", 192), ("ResNet50", 257), ("ResNet50", 1024), ("ResNet50", 1001), ("ResNet101", 128), ("ResNet152", 64),
+                                     ("ResNet50", 192), ("ResNet50", 257), ("ResNet50", 1024), ("ResNet50", 1001), ("ResNet50", 2048), ("ResNet50", 3000), ("ResNet101", 128), ("ResNet152", 64),
                                      ("ResNet101", 200), ("ResNet152", 176), ("ResNet152", 320)])
 def test_resident_stage_matches_tiled_kernels(eng, synth, model, n):
-    """512, 1024: two images a workgroup (one and two rounds of workgroups); 257, 301, 1001: an odd batch, the last
+    """512, 1024, 2048, 3000: two images a workgroup (one, two, four, six rounds of workgroups); 257, 301, 1001: an odd batch, the last
     workgroup with one image; up to one image per CU: one image a workgroup; ResNet152 from 160 images on: a second
     stage of eight blocks in the launch."""
     x = _images(n)

@@ -298,6 +298,46 @@ def test_distance_diagnostic_sizes(mods, n, d, parts):
     assert (got[:, 0] == got[0, 0]).all() and (got[:, 1] == got[0, 1]).all()  # every rank, the same bits
 
 
+@pytest.mark.parametrize("n", [40, 300])
+def test_diagnostic_of_the_fused_loop_in_any_chunking(mods, synth, n):
+    """The fused loop adds up an iteration's tile sums in the NEXT iteration's distance launch (the last one's in a
+    launch of its own): whole, in chunks of one and in uneven chunks it leaves the same bits, and they are the mean
+    distance of the positions the history holds; with early stopping nothing is written past the stop."""
+    eng = mods["eng"]
+    dev = torch.device("cuda:0")
+    d, iters = 10, 9
+    ev = eng.Evaluator(eng.PackedGenerator(synth.generator_state(d, 1, 64, seed=11), dev),
+                       eng.PackedAssessor(synth.resnet_state("ResNet50", 1, 8, seed=12), dev, img_side=28))
+    spec = eng.FitnessSpec(class_index=2)
+    r = np.random.RandomState(3).standard_normal((n, 2, d))
+
+    def run(chunks, early=False, tol=1e-5):
+        sw = eng.HipSwarm(ev, n, d, iters, history=True, diagnostics=True)
+        sw.load(r[:, 0], (r[:, 1] - 0.5) / 10, 0.73)
+        first = 1
+        for count in chunks:
+            sw.iterate(first, count, spec, 1.496, 1.496, True, early, tol, True, seed=5)
+            first += count
+        torch.cuda.synchronize()
+        res = sw.results()
+        return res
+
+    whole = run([iters])
+    for chunks in ([1] * iters, [2, 1, 4, 2], [8, 1]):
+        got = run(chunks)
+        np.testing.assert_array_equal(got["mean_mse"], whole["mean_mse"])
+        np.testing.assert_array_equal(got["hist_pos"], whole["hist_pos"])
+    hp = np.asarray(whole["hist_pos"])  # [iters + 1, n, d]
+    want = [torch.pdist(torch.from_numpy(np.ascontiguousarray(hp[i]))).mean().item() for i in range(1, iters + 1)]
+    np.testing.assert_allclose(np.asarray(whole["mean_mse"])[:iters], want, rtol=1e-13)
+    # a tolerance no improvement reaches: the loop stops early, in every chunking at the same iteration with the same values
+    stopped = run([iters], early=True, tol=1e9)
+    again = run([1] * iters, early=True, tol=1e9)
+    assert stopped["stopped"] and 1 <= stopped["iters"] < iters and again["iters"] == stopped["iters"]
+    np.testing.assert_array_equal(again["mean_mse"], stopped["mean_mse"])
+    np.testing.assert_array_equal(stopped["mean_mse"], np.asarray(whole["mean_mse"])[:stopped["iters"]])
+
+
 def test_many_particles_take_the_multi_workgroup_kernels(mods):
     """More particles than the one-workgroup kernels take (4096): personal bests, candidate record,
     global best and move through pbest_kernel / candidate_kernel / global_best_kernel / move_kernel,
