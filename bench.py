@@ -452,8 +452,9 @@ def main():
                     "`frac` prices the launches against the 16-bit MFMA peak all the same",
                     "kernel": f"every convolution launch of an iteration ({args.dtype}-input MFMA): conv_chain_kernel (the late ResNet stages in one "
                               "persistent launch of the implicit-GEMM tile code), stage_resident_kernel (stem + first two stages, two images' maps "
-                              "resident in a workgroup's LDS; 28x28 images) and conv_gemm_kernel / _pair / _fused (the same tile code, one launch a "
-                              "layer: the generator, and whatever the two above do not cover at this size)",
+                              "resident in a workgroup's LDS; 28x28 images), gen_resident_kernel (the generator's three layers the same way, "
+                              "first and last layer included in its FLOPs and its time) and conv_gemm_kernel / _pair / _fused (the same tile "
+                              "code, one launch a layer: whatever the three above do not cover at this size)",
                     "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic,
                     "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE" + (", profiles/" + traffic_file if traffic_file else "; no PMC summary of this configuration") + ")",

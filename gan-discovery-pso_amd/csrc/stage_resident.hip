@@ -961,7 +961,9 @@ static bool g_gr_enabled = [] {
 struct ResidentGenerator {
     int dtype;
     GrArgs args;  // weights filled in; latents / first map, outputs and n per launch
-    double flops, executed2, executed1, weight_bytes;  // second layer, per image: nominal, multiplied with two / one image a workgroup
+    // per image: nominal FLOPs of the second and last layer (and of the first, when the launch computes it: first_flops),
+    // FLOPs issued to the matrix cores with two / one image a workgroup (second and last layer; the first is vector ALU work)
+    double flops, first_flops, executed2, executed1, weight_bytes;
 };
 
 bool resident_generator_enabled() { return g_gr_enabled; }
@@ -1039,9 +1041,11 @@ int resident_generator_new(DeviceArena &arena, int dtype, int z_dim, const float
         delete g;
         return rc;
     }
-    g->flops = l2->flops_nominal;
-    g->executed2 = 2.0 * 4 * 16 * (5 + 0.5 + 0.5) / 2 * GR_C2 * K;  // 5 row blocks with four taps, 2 with two
-    g->executed1 = 2.0 * 4 * 64 * GR_C2 * K;
+    const double last_nominal = 2.0 * GR_NPIX * 4 * GR_C2, last_executed = 2.0 * GR_NBLK * 16 * 16 * GR_C2;  // 4 taps a pixel; 13 blocks x 16 positions
+    g->flops = l2->flops_nominal + last_nominal;
+    g->first_flops = 2.0 * z_dim * GR_NCOL;
+    g->executed2 = 2.0 * 4 * 16 * (5 + 0.5 + 0.5) / 2 * GR_C2 * K + last_executed;  // 5 row blocks with four taps, 2 with two
+    g->executed1 = 2.0 * 4 * 64 * GR_C2 * K + last_executed;
     g->weight_bytes = (double)es * 4 * GR_C2 * K;
     *out = g;
     return GDPSO_OK;
@@ -1066,7 +1070,7 @@ int launch_resident_generator(const ResidentGenerator *g, hipStream_t stream, in
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool timed = conv_timing_slot(&e0, &e1);
     if (timed)
-        conv_timing_account(g->flops * n_images, (images_per_wg == 2 ? g->executed2 : g->executed1) * n_images,
+        conv_timing_account((g->flops + (z ? g->first_flops : 0.0)) * n_images, (images_per_wg == 2 ? g->executed2 : g->executed1) * n_images,
                             g->weight_bytes + (double)n_images * (dtype_size(g->dtype) * (a1 ? (double)RS_PIX * GR_C1 : 0.0) + 8.0 * GR_NPIX));
 #define GDPSO_GR_LAUNCH(IMG)                                                                                                          \
     if (timed) {                                                                                                                      \

@@ -10,8 +10,9 @@ v_mfma_f32_32x32x2_f32 (4096 FLOP), 32 per v_mfma_f32_16x16x4_f32 (2048 FLOP): 6
 busy cycles x 64 = FLOPs the matrix pipes really executed.  16-bit: 32 per v_mfma_f32_32x32x16_bf16 /
 _f16 (32768 FLOP): 1024 FLOP a cycle.  (The counter pass's own GRBM_GUI_ACTIVE is no use as the
 denominator: it includes ~9 us of per-dispatch serialisation that a normal run does not have.)
-(stage_resident_kernel with 16-bit storage mixes the two: its stem runs fp32 MFMAs, the stages 16-bit ones; its row is
-priced at the 16-bit rate like the other convolution launches and so understates the stem's share.)
+(stage_resident_kernel and gen_resident_kernel with 16-bit storage mix the two: the stem and the generator's last layer
+run fp32 MFMAs, the rest 16-bit ones; their rows are priced at the 16-bit rate like the other convolution launches and
+so understate the fp32 layers' share.)
 utilisation = executed FLOP/s over the peak of the operand type (157.3 / 2500 TFLOP/s at 2.4 GHz; the
 chip holds ~2.1 GHz under the fp32 load, so 0.875 is the ceiling there).
 
@@ -74,7 +75,7 @@ def main():
         tf = flop / avg_ns[k] / 1e3
         out["kernels"][k] = {"launches_counted": n[k], "avg_us": round(avg_ns[k] / 1e3, 2), "executed_gflop_per_launch": round(flop / 1e9, 3),
                              "executed_tflops": round(tf, 1), "mfma_util": round(tf / p, 3)}
-        if "conv_gemm" in k or "conv_chain" in k or "stage_resident" in k:
+        if "conv_gemm" in k or "conv_chain" in k or "stage_resident" in k or "gen_resident" in k:
             tot_flop += flop * n[k]
             tot_ns += avg_ns[k] * n[k]
     out["kernels"]["conv_gemm (all instantiations)"] = {"executed_tflops": round(tot_flop / tot_ns / 1e3, 1),

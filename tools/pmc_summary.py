@@ -28,16 +28,16 @@ def main():
     out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (one pass each) -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline",
            "corrections": "counter values are KiB; FETCH_SIZE doubled (gfx950 tallies 128-B requests of 16-B-per-lane reads at 64 B); WRITE_SIZE as read",
            "kernels": {}}
-    # every convolution launch (tile shapes, paired launches, the chained launch, the resident stages) as one entry
+    # every convolution launch (tile shapes, paired launches, the chained launch, the resident stages and generator) as one entry
     for a in (fe, wr):
         tot = [0, 0.0]
         for k in list(a):
-            if "conv_gemm" in k or "conv_chain" in k or "stage_resident" in k:
+            if "conv_gemm" in k or "conv_chain" in k or "stage_resident" in k or "gen_resident" in k:
                 tot[0] += a[k][0]
                 tot[1] += a[k][1]
         a["conv_gemm (all instantiations)"] = tot
     for k in fe:
-        if fe[k][1] <= 0 or not (k.startswith("gdpso::") or k.startswith("conv_gemm") or k.startswith("conv_chain") or "stage_resident" in k):
+        if fe[k][1] <= 0 or not (k.startswith("gdpso::") or k.startswith("conv_gemm") or k.startswith("conv_chain") or "stage_resident" in k or "gen_resident" in k):
             continue
         c, v = fe[k]
         cw, vw = wr.get(k, [c, 0.0])

@@ -14,9 +14,16 @@ def main():
     full = "--full" in sys.argv
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    # an iteration begins with the generator's first kernel (latents in): gen_first_kernel, or latent_prep ahead
-    # of a first layer on the matrix cores
-    idx = [i for i, r in enumerate(rows) if "latent_prep" in r["Kernel_Name"] or "gen_first_kernel" in r["Kernel_Name"]]
+    # an iteration begins with the generator's first kernel (latents in): gen_resident_kernel (the whole generator), or
+    # gen_first_kernel, or latent_prep ahead of a first layer on the matrix cores (gen_resident_kernel then follows
+    # within two launches and is not a beginning)
+    idx = []
+    for i, r in enumerate(rows):
+        k = r["Kernel_Name"]
+        if "latent_prep" in k or "gen_first_kernel" in k:
+            idx.append(i)
+        elif "gen_resident" in k and not any("latent_prep" in q["Kernel_Name"] for q in rows[max(0, i - 2):i]):
+            idx.append(i)
     if len(idx) < 2:
         raise SystemExit("fewer than two iterations in the trace")
     # the stretches between two generator passes that hold a PSO step (the benchmark ends with passes of
