@@ -198,7 +198,7 @@ bool resident_stage_has_second(const ResidentStage *s);
 void resident_stage_free(ResidentStage *s);
 // img01: the [n][28][28] images; out: the stage's NHWC output; zero / zero_quads: 16-byte words the launch clears on its way.
 // second: go on through the second stage (out: that stage's output); only with resident_stage_has_second.
-int launch_resident_stage(const ResidentStage *s, hipStream_t stream, int n_images, int images_per_wg, bool second, const float *img01,
+int launch_resident_stage(const ResidentStage *s, hipStream_t stream, int n_images, int images_per_wg, int num_cus, bool second, const float *img01,
                           void *out, void *zero, int zero_quads);
 // Whether a batch planned as n_images should take the second stage along.
 bool resident_stage_second(const ResidentStage *s, int n_images);
@@ -213,7 +213,7 @@ int resident_generator_new(DeviceArena &arena, int dtype, int z_dim, const float
                            const ConvLayer *l2, const float *w5, float b5, ResidentGenerator **out);
 void resident_generator_free(ResidentGenerator *g);
 // z (latents, z_dim <= 16) or a1 (the first layer's output, elements of the network's type): one of them, the other null.
-int launch_resident_generator(const ResidentGenerator *g, hipStream_t stream, int n_images, int images_per_wg, const void *z, int z_is_f64,
+int launch_resident_generator(const ResidentGenerator *g, hipStream_t stream, int n_images, int images_per_wg, int num_cus, const void *z, int z_is_f64,
                               const void *a1, float *img, float *img01, const float *target, float *mse);
 
 // host-side helpers (pack.cpp)

@@ -893,12 +893,12 @@ extern "C" int gdpso_generator_forward(const gdpso_generator *g, void *stream_, 
     const int resident_images = g->resident && resident_generator_enabled() ? resident_stage_images(plan_batch(n), g->num_cus) : 0;
     if (resident_images > 0) {
         if (g->first_direct)
-            return launch_resident_generator(g->resident, stream, n, resident_images, z, z_is_f64, nullptr, img, img01, target, mse);
+            return launch_resident_generator(g->resident, stream, n, resident_images, g->num_cus, z, z_is_f64, nullptr, img, img01, target, mse);
         const long ne = (long)n * g->kpad;
         GDPSO_WITH_DTYPE(g->dtype, hipLaunchKernelGGL(latent_prep_kernel<E>, dim3(ceil_div(ne, 256)), dim3(256), 0, stream, z, z_is_f64, n,
                                                       g->z_dim, g->kpad, (E *)zpad));
         if ((rc = launch_conv(l1, stream, n, zpad, nullptr, a1, sk))) return rc;
-        return launch_resident_generator(g->resident, stream, n, resident_images, nullptr, 0, a1, img, img01, target, mse);
+        return launch_resident_generator(g->resident, stream, n, resident_images, g->num_cus, nullptr, 0, a1, img, img01, target, mse);
     }
     if (g->first_direct) {
         const int ncol = g->k1 * g->k1 * 2 * g->features;
@@ -1046,7 +1046,14 @@ std::shared_ptr<const AssLayout> ass_layout(const gdpso_assessor *a, int n) {
     // (a chain picks up behind the resident launch: behind the first stage, or behind the second)
     L.resident_second = L.resident && resident_stage_second(a->resident, plan_batch(n));
     L.chain_first = L.resident ? (L.resident_second ? a->resident_blocks : a->chain_first) : a->chain_first;
-    if (a->kind == 0 && chain_enabled() && L.chain_first > 0 && L.chain_first < (int)L.blocks.size()) {
+    // (large batches: the chain's steps hold many tiles per workgroup, and the launches per layer, whose cost per layer no
+    // longer matters there, deal them better: behind the resident launch +4 % at 2304 ... 3072 images in fp32, +8 % with
+    // 16-bit storage, even at 2048.  GDPSO_CHAIN_MAX_IMAGES, by the planned batch)
+    static const int chain_max_images = [] {
+        const char *e = getenv("GDPSO_CHAIN_MAX_IMAGES");
+        return e ? atoi(e) : 2048;
+    }();
+    if (a->kind == 0 && chain_enabled() && L.chain_first > 0 && L.chain_first < (int)L.blocks.size() && plan_batch(n) <= chain_max_images) {
         size_t zmax = 0;
         for (size_t i = L.chain_first; i < L.blocks.size(); ++i) zmax = std::max(zmax, out_elems(L.blocks[i].c3));
         int nteams = 0;
@@ -1382,7 +1389,7 @@ static int assessor_forward_impl(const gdpso_assessor *a, void *stream_, int n, 
         // stem and first stages in one launch; its output lies where the tiled kernels would have left it (in x
         // after an even number of blocks, else in y)
         if (L.chain_first % 2 == 1) std::swap(x, y);
-        if ((rc = launch_resident_stage(a->resident, stream, n, L.resident_images, L.resident_second, img01, x, ctl_zero, ctl_quads))) return rc;
+        if ((rc = launch_resident_stage(a->resident, stream, n, L.resident_images, a->num_cus, L.resident_second, img01, x, ctl_zero, ctl_quads))) return rc;
     } else if (stem_mfma && mfma_smem <= stem_lds_max) {
         GDPSO_WITH_DTYPE(a->dtype, hipLaunchKernelGGL(stem_mfma_kernel<E>, dim3(n), dim3(512), mfma_smem, stream, img01, a->stem_w,
                                                       a->stem_scale, a->stem_shift, a->side, a->ho, a->hp, mps, mfma_band,

@@ -888,17 +888,33 @@ int resident_stage_new(DeviceArena &arena, int dtype, int nblocks, const float *
     return GDPSO_OK;
 }
 
+// A last round of at most one image per CU runs with ONE image a workgroup (GDPSO_RESIDENT_TAIL=0: with two like the rest).
+static bool g_rs_tail_single = [] {
+    const char *e = getenv("GDPSO_RESIDENT_TAIL");
+    return e ? e[0] != '0' : true;
+}();
+
+// Of a batch served two images a workgroup, how many images (the last ones) form a last round that one image a
+// workgroup serves faster: the remainder behind whole rounds of 2 x num_cus images, when it is at most num_cus.
+static int resident_tail_images(int n_images, int images_per_wg, int num_cus) {
+    if (!g_rs_tail_single || g_rs_force_images > 0 || images_per_wg != 2 || num_cus <= 0 || n_images <= 2 * num_cus) return 0;
+    const int r = n_images % (2 * num_cus);
+    return r <= num_cus ? r : 0;
+}
+
 // How many images a workgroup of the resident launch should take for a batch planned as n_images on a device of
 // num_cus CUs: 0 (the tiled kernels serve the batch better), 1 or 2.  A workgroup holds its CU for the whole run of
 // layers, so the launch takes rounds x (time of one workgroup): one image a workgroup while that still leaves every
-// image a CU of its own, two up to two images per CU; beyond, whole rounds of 2 x num_cus images, worth it only
-// when the last round is nearly full (measured on MI355X, 256 CUs, fp32: 64 ... 256 images one a workgroup, ... 512
-// two; 768 images = 1.5 rounds lose to the tiled kernels, 1280 = 2.5 rounds come out even, whole rounds win).
+// image a CU of its own, two up to two images per CU; beyond, whole rounds of 2 x num_cus images and a last round
+// of one or two images a workgroup (resident_tail_images; a one-image round takes 0.62 of a two-image one).  Measured
+// on MI355X (256 CUs, fp32) against the tiled kernels at 600 ... 16384 images: ahead at every size, by 0.5 % (600
+// images: a last round of 88 workgroups) to 9 % (768).  Without the one-image last round (GDPSO_RESIDENT_TAIL=0)
+// only batches whose rounds come out at least 85 % full take the launch (768 images: 6 % behind the tiled kernels).
 int resident_stage_images(int n_images, int num_cus) {
     if (n_images < g_rs_min_images || n_images > g_rs_max_images) return 0;
     if (g_rs_force_images > 0) return g_rs_force_images;
     if (n_images <= num_cus) return 1;
-    if (n_images <= 2 * num_cus) return 2;
+    if (n_images <= 2 * num_cus || g_rs_tail_single) return 2;
     const long capacity = (long)ceil_div(ceil_div(n_images, 2), num_cus) * 2 * num_cus;
     return (long)n_images * 100 >= capacity * 85 ? 2 : 0;
 }
@@ -908,10 +924,8 @@ int resident_stage_images(int n_images, int num_cus) {
 // even at 128 images, +6 % at 192, +5 % at 256).
 bool resident_stage_second(const ResidentStage *s, int n_images) { return s != nullptr && s->stage2 && n_images >= g_rs2_min_images; }
 
-int launch_resident_stage(const ResidentStage *s, hipStream_t stream, int n_images, int images_per_wg, bool second, const float *img01,
-                          void *out, void *zero, int zero_quads) {
-    if (images_per_wg != 1 && images_per_wg != 2) return fail(GDPSO_ERR_ARG, "resident stage: one or two images a workgroup");
-    if (second && !s->stage2) return fail(GDPSO_ERR_ARG, "resident stage: the handle holds no second stage");
+static int launch_resident_stage_part(const ResidentStage *s, hipStream_t stream, int n_images, int images_per_wg, bool second,
+                                      const float *img01, void *out, void *zero, int zero_quads) {
     RsArgs a = s->args;
     a.img01 = img01;
     a.out = out;
@@ -950,6 +964,19 @@ int launch_resident_stage(const ResidentStage *s, hipStream_t stream, int n_imag
 #undef GDPSO_RS_LAUNCH
     GDPSO_HIP(hipGetLastError());
     return GDPSO_OK;
+}
+
+int launch_resident_stage(const ResidentStage *s, hipStream_t stream, int n_images, int images_per_wg, int num_cus, bool second,
+                          const float *img01, void *out, void *zero, int zero_quads) {
+    if (images_per_wg != 1 && images_per_wg != 2) return fail(GDPSO_ERR_ARG, "resident stage: one or two images a workgroup");
+    if (second && !s->stage2) return fail(GDPSO_ERR_ARG, "resident stage: the handle holds no second stage");
+    // whole rounds two images a workgroup, a short last round one image a workgroup in a launch of its own behind it
+    const int tail = resident_tail_images(n_images, images_per_wg, num_cus), head = n_images - tail;
+    int rc = launch_resident_stage_part(s, stream, head, images_per_wg, second, img01, out, zero, zero_quads);
+    if (rc || tail == 0) return rc;
+    const size_t out_bytes = (size_t)(second ? RS2_PIX * 512 : RS_PIX * 256) * dtype_size(s->dtype);
+    return launch_resident_stage_part(s, stream, tail, 1, second, img01 + (size_t)head * ST_SIDE * ST_SIDE, (char *)out + (size_t)head * out_bytes,
+                                      nullptr, 0);
 }
 
 // ---- the resident generator (host side)
@@ -1052,11 +1079,8 @@ int resident_generator_new(DeviceArena &arena, int dtype, int z_dim, const float
 }
 
 // z (latents, z_dim <= 16 only) or a1 (the first layer's output) is given, the other null.
-int launch_resident_generator(const ResidentGenerator *g, hipStream_t stream, int n_images, int images_per_wg, const void *z, int z_is_f64,
-                              const void *a1, float *img, float *img01, const float *target, float *mse) {
-    if (images_per_wg != 1 && images_per_wg != 2) return fail(GDPSO_ERR_ARG, "resident generator: one or two images a workgroup");
-    if ((z == nullptr) == (a1 == nullptr)) return fail(GDPSO_ERR_ARG, "resident generator: latents or the first map, not both");
-    if (z != nullptr && g->args.zd > GR_MAX_Z) return fail(GDPSO_ERR_ARG, "resident generator: latents of more than 16 dimensions");
+static int launch_resident_generator_part(const ResidentGenerator *g, hipStream_t stream, int n_images, int images_per_wg, const void *z,
+                                          int z_is_f64, const void *a1, float *img, float *img01, const float *target, float *mse) {
     GrArgs a = g->args;
     a.z = z;
     a.z_is_f64 = z_is_f64;
@@ -1086,6 +1110,20 @@ int launch_resident_generator(const ResidentGenerator *g, hipStream_t stream, in
 #undef GDPSO_GR_LAUNCH
     GDPSO_HIP(hipGetLastError());
     return GDPSO_OK;
+}
+
+int launch_resident_generator(const ResidentGenerator *g, hipStream_t stream, int n_images, int images_per_wg, int num_cus, const void *z,
+                              int z_is_f64, const void *a1, float *img, float *img01, const float *target, float *mse) {
+    if (images_per_wg != 1 && images_per_wg != 2) return fail(GDPSO_ERR_ARG, "resident generator: one or two images a workgroup");
+    if ((z == nullptr) == (a1 == nullptr)) return fail(GDPSO_ERR_ARG, "resident generator: latents or the first map, not both");
+    if (z != nullptr && g->args.zd > GR_MAX_Z) return fail(GDPSO_ERR_ARG, "resident generator: latents of more than 16 dimensions");
+    const int tail = resident_tail_images(n_images, images_per_wg, num_cus), head = n_images - tail;
+    int rc = launch_resident_generator_part(g, stream, head, images_per_wg, z, z_is_f64, a1, img, img01, target, mse);
+    if (rc || tail == 0) return rc;
+    const size_t zb = (size_t)head * g->args.zd * (z_is_f64 ? 8 : 4), ab = (size_t)head * RS_PIX * GR_C1 * dtype_size(g->dtype);
+    const size_t px = (size_t)head * GR_NPIX;
+    return launch_resident_generator_part(g, stream, tail, 1, z ? (const char *)z + zb : nullptr, z_is_f64, a1 ? (const char *)a1 + ab : nullptr,
+                                          img ? img + px : nullptr, img01 + px, target ? target + px : nullptr, mse ? mse + head : nullptr);
 }
 
 }  // namespace gdpso

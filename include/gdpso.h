@@ -415,8 +415,8 @@ int gdpso_plan_options(int plan_images, int splitk);
  * max_images / min_images > 0: the largest / smallest (planned, see gdpso_plan_options) batch that takes the
  * resident kernel; 0 keeps the current limit (defaults: no upper limit, 64 below: smaller batches leave most CUs
  * without a workgroup; a workgroup takes one image up to one image per CU, two beyond, and batches of more than
- * two images per CU take the launch only when its rounds of workgroups come out at least 85 % full: 768 images on
- * 256 CUs go to the tiled kernels, 1024 or 4096 to the resident launch).  The paths
+ * two images per CU run in rounds of two images a workgroup with a last round of at most one image per CU as a
+ * launch of its own with one image a workgroup).  The paths
  * add a row's products in different orders and agree to fp32 rounding (to the element type's rounding for 16-bit
  * storage).  Environment: GDPSO_STAGE1_RESIDENT (0: none), GDPSO_STAGE2_RESIDENT (0: first stage only),
  * GDPSO_STAGE1_RESIDENT_MAX, GDPSO_STAGE1_RESIDENT_MIN give the initial values. */

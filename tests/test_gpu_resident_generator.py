@@ -71,9 +71,10 @@ def test_reference_activations(eng, synth, tag, zd):
 
 
 @pytest.mark.parametrize("zd", [10, 100, 16, 3])
-@pytest.mark.parametrize("n", [1, 2, 37, 256, 257, 512, 1001, 2048])
+@pytest.mark.parametrize("n", [1, 2, 37, 256, 257, 512, 700, 1001, 2048])
 def test_matches_tiled_kernels_and_oracle(eng, synth, oracle, zd, n):
-    """One image a workgroup (up to one per CU), two (beyond), an odd batch whose last workgroup holds one image;
+    """One image a workgroup (up to one per CU), two (beyond), an odd batch whose last workgroup holds one image, a
+    short last round in a launch of its own with one image a workgroup (700 on 256 CUs: 512 + 188);
     float64 latents like the reference's numpy positions, float32 ones as well."""
     ev = _evaluator(eng, synth, zd)
     zh = np.random.RandomState(100 * zd + n).standard_normal((n, zd))

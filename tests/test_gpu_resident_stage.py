@@ -111,15 +111,33 @@ def test_an_image_gets_the_same_bits_in_any_batch(eng, synth):
 
 
 def test_limits_send_batches_to_the_tiled_kernels(eng, synth):
-    """Above max_images, below min_images and at a batch of one and a half rounds of workgroups (768 images on 256
-    CUs) the tiled kernels run; one image and two images a workgroup give a row the same bits."""
+    """Above max_images and below min_images the tiled kernels run."""
     x = _images(64)
     tiled = _logits(eng, synth, "ResNet50", x, resident=0)
     np.testing.assert_array_equal(_logits(eng, synth, "ResNet50", x, resident=2, max_images=32), tiled)
     np.testing.assert_array_equal(_logits(eng, synth, "ResNet50", x, resident=2, min_images=65), tiled)
+
+
+@pytest.mark.parametrize("extra", [0, 1, 37])
+def test_short_last_round_takes_one_image_a_workgroup(eng, synth, extra):
+    """One and a half rounds of workgroups (768 images on 256 CUs, and a few more): whole rounds two images a
+    workgroup, the rest one image a workgroup in a launch of its own behind it; the same bits as every workgroup
+    with two images, or every workgroup with one."""
+    if os.environ.get("GDPSO_RESIDENT_TAIL", "1") == "0":
+        pytest.skip("the one-image last round is switched off in this process")
+    lib = importlib.import_module("gan-discovery-pso_amd._lib")
     cus = torch.cuda.get_device_properties(0).multi_processor_count
-    x = _images(3 * cus)
-    np.testing.assert_array_equal(_logits(eng, synth, "ResNet50", x, resident=2, max_images=8 * cus), _logits(eng, synth, "ResNet50", x, resident=0))
+    x = _images(3 * cus + extra)
+    mixed = _logits(eng, synth, "ResNet50", x, resident=2)
+    tiled = _logits(eng, synth, "ResNet50", x, resident=0)
+    np.testing.assert_allclose(mixed, tiled, rtol=1e-4, atol=2e-4)
+    assert not np.array_equal(mixed, tiled)
+    for images in (1, 2):
+        lib.check(lib.lib().gdpso_resident_force_images(images))
+        try:
+            np.testing.assert_array_equal(_logits(eng, synth, "ResNet50", x, resident=2), mixed)
+        finally:
+            lib.check(lib.lib().gdpso_resident_force_images(0))
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])

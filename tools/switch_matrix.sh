@@ -24,4 +24,5 @@ run GDPSO_STAGE1_RESIDENT_MIN=1 GDPSO_STAGE2_RESIDENT_MIN=1
 run GDPSO_STEM_LDS_KB=64 GDPSO_STAGE1_RESIDENT=0
 run GDPSO_GEN_RESIDENT=0
 run GDPSO_DIST_DEFER=0 GDPSO_STAGE1_RESIDENT_MAX=1024
+run GDPSO_RESIDENT_TAIL=0 GDPSO_CHAIN_MAX_IMAGES=1000000
 cat $OUT
