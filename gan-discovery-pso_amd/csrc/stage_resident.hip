@@ -11,7 +11,8 @@
 // layers, and the launch is n / 2 workgroups (one per CU at the 512 particles of the headline configuration)
 // where the tiled kernels need a launch per layer (tiles of 64 rows: 1.5 per CU in the first stage) or the
 // chained launch a hand-off between workgroups per layer.  Smaller batches give a workgroup ONE image (4 and 1 row
-// blocks) so that every image still has a CU of its own; see resident_stage_images.
+// blocks) so that every image still has a CU of its own; larger ones run in rounds of workgroups, the last round, when
+// it holds at most one image per CU, as a launch of its own with one image a workgroup; see resident_stage_images.
 //
 // Arithmetic: v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulation).  The A operand of every
 // layer is read from LDS where the previous layer's epilogue left it (rows padded by 16 bytes: conflict-free
@@ -538,10 +539,11 @@ struct GrLds {
     static constexpr size_t A1_BYTES = (size_t)(RS_ROWS + 1) * LDA1 * sizeof(E), A2_OFF = A1_BYTES;
     static constexpr size_t A2_BYTES = (size_t)RS_IMAGES * GR_NIN * LDA2 * sizeof(E), ROWS_OFF = A2_OFF + A2_BYTES;
     static constexpr size_t BYTES = ROWS_OFF + 4 * 112 * sizeof(short);  // (behind the maps: the phases' row orders, see GrArgs::rows)
-    // the last layer's products [2 x 208][16] floats, one image [784] floats and the reduction slots lie where the first
-    // map was (and, with 16-bit storage, run on into the second map, which is dead by the time they are written)
-    static constexpr size_t SC_OFF = 0, SC_BYTES = (size_t)RS_IMAGES * GR_NBLK * 16 * 16 * 4, SIMG_OFF = SC_BYTES, SRED_OFF = SIMG_OFF + GR_NPIX * 4;
-    static_assert(SC_BYTES <= A2_OFF && SRED_OFF + 128 <= ROWS_OFF && BYTES <= 160 * 1024, "LDS layout");
+    // the last layer's products [2 x 208][16] floats, the two images [2][784] floats and the reduction slots lie where the
+    // first map was (and, with 16-bit storage, run on into the second map, which is dead by the time they are written)
+    static constexpr size_t SC_OFF = 0, SC_BYTES = (size_t)RS_IMAGES * GR_NBLK * 16 * 16 * 4, SIMG_OFF = SC_BYTES;
+    static constexpr size_t SRED_OFF = SIMG_OFF + (size_t)RS_IMAGES * GR_NPIX * 4;
+    static_assert(SC_BYTES <= A2_OFF && SRED_OFF + RS_IMAGES * 24 * 4 <= ROWS_OFF && BYTES <= 160 * 1024, "LDS layout");
 };
 
 struct GrArgs {
@@ -580,7 +582,11 @@ __global__ __launch_bounds__(512) void gen_resident_kernel(const GrArgs a) {
             s_z[tid] = (float)(E)v;  // (16-bit storage: the latent rounded as the matrix-core path rounds its A operand)
         }
         __syncthreads();
-        for (int q = tid; q < GR_NCOL / 4; q += 512) {
+        constexpr int NQ = GR_NCOL / 4;  // 1568 quads of columns: three passes of the workgroup and 32 quads more
+#pragma unroll
+        for (int pass = 0; pass < (NQ + 511) / 512; ++pass) {
+            const int q = tid + 512 * pass;
+            if (512 * (pass + 1) > NQ && q >= NQ) break;
             const int col = q * 4;
             f32x4 w[GR_MAX_Z];
 #pragma unroll
@@ -689,13 +695,16 @@ __global__ __launch_bounds__(512) void gen_resident_kernel(const GrArgs a) {
         }
     }
     __syncthreads();
-    // ---- per image: gather the four contributions of every output pixel, bias + tanh, min / max, rescale
-    for (int im = 0; im < nimg; ++im) {
-        const int n = img0 + im;
-        const float *sc_im = s_c + im * GR_NBLK * 16 * 16;
-        float mn = INFINITY, mx = -INFINITY, se = 0.f;
-        float *dst = a.img ? a.img + (size_t)n * GR_NPIX : nullptr;
-        const float *tg = a.target ? a.target + (size_t)n * GR_NPIX : nullptr;
+    // ---- gather the four contributions of every output pixel, bias + tanh, min / max, rescale: thread t takes pixels
+    // t and t + 512 of both images (an image's sums run in the same order whichever place it has in the workgroup)
+    {
+        float mn[IMG], mx[IMG], se[IMG];
+#pragma unroll
+        for (int im = 0; im < IMG; ++im) {
+            mn[im] = INFINITY;
+            mx[im] = -INFINITY;
+            se[im] = 0.f;
+        }
         for (int i = tid; i < GR_NPIX; i += 512) {
             const int oy = i / GR_SIDE, ox = i - oy * GR_SIDE;
             const int py = oy & 1, my = oy >> 1, px = ox & 1, mxx = ox >> 1;
@@ -703,46 +712,60 @@ __global__ __launch_bounds__(512) void gen_resident_kernel(const GrArgs a) {
             const int iy1 = my + (py ? 1 : -1), ky0 = py ? 2 : 1, ky1 = py ? 0 : 3;
             const int ix1 = mxx + (px ? 1 : -1), kx0 = px ? 2 : 1, kx1 = px ? 0 : 3;
             const bool yok = (unsigned)iy1 < (unsigned)GR_HIN, xok = (unsigned)ix1 < (unsigned)GR_HIN;
-            const float t00 = sc_im[(my * GR_HIN + mxx) * 16 + ky0 * 4 + kx0];
-            const float t01 = xok ? sc_im[(my * GR_HIN + ix1) * 16 + ky0 * 4 + kx1] : 0.f;
-            const float t10 = yok ? sc_im[(iy1 * GR_HIN + mxx) * 16 + ky1 * 4 + kx0] : 0.f;
-            const float t11 = (yok && xok) ? sc_im[(iy1 * GR_HIN + ix1) * 16 + ky1 * 4 + kx1] : 0.f;
-            const float v = tanhf(((t00 + t01) + (t10 + t11)) + a.b5);
-            s_img[i] = v;
-            mn = fminf(mn, v);
-            mx = fmaxf(mx, v);
-            if (dst) dst[i] = v;
-            if (tg) {
-                const float dlt = tg[i] - v;
-                se = fmaf(dlt, dlt, se);
+            const int o00 = (my * GR_HIN + mxx) * 16 + ky0 * 4 + kx0, o01 = (my * GR_HIN + ix1) * 16 + ky0 * 4 + kx1;
+            const int o10 = (iy1 * GR_HIN + mxx) * 16 + ky1 * 4 + kx0, o11 = (iy1 * GR_HIN + ix1) * 16 + ky1 * 4 + kx1;
+#pragma unroll
+            for (int im = 0; im < IMG; ++im) {
+                if (im < nimg) {
+                    const float *sc_im = s_c + im * GR_NBLK * 16 * 16;
+                    const float t00 = sc_im[o00];
+                    const float t01 = xok ? sc_im[o01] : 0.f;
+                    const float t10 = yok ? sc_im[o10] : 0.f;
+                    const float t11 = (yok && xok) ? sc_im[o11] : 0.f;
+                    const float v = tanhf(((t00 + t01) + (t10 + t11)) + a.b5);
+                    s_img[im * GR_NPIX + i] = v;
+                    mn[im] = fminf(mn[im], v);
+                    mx[im] = fmaxf(mx[im], v);
+                    if (a.img) a.img[(size_t)(img0 + im) * GR_NPIX + i] = v;
+                    if (a.target) {
+                        const float dlt = a.target[(size_t)(img0 + im) * GR_NPIX + i] - v;
+                        se[im] = fmaf(dlt, dlt, se[im]);
+                    }
+                }
             }
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            mn = fminf(mn, __shfl_xor(mn, o));
-            mx = fmaxf(mx, __shfl_xor(mx, o));
-            se += __shfl_xor(se, o);
-        }
-        if (lane == 0) {
-            s_red[wave] = mn;
-            s_red[8 + wave] = mx;
-            s_red[16 + wave] = se;
+        for (int im = 0; im < IMG; ++im) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                mn[im] = fminf(mn[im], __shfl_xor(mn[im], o));
+                mx[im] = fmaxf(mx[im], __shfl_xor(mx[im], o));
+                se[im] += __shfl_xor(se[im], o);
+            }
+            if (lane == 0) {
+                s_red[im * 24 + wave] = mn[im];
+                s_red[im * 24 + 8 + wave] = mx[im];
+                s_red[im * 24 + 16 + wave] = se[im];
+            }
         }
         __syncthreads();
-        mn = s_red[0];
-        mx = s_red[8];
-        se = s_red[16];
 #pragma unroll
-        for (int k = 1; k < 8; ++k) {
-            mn = fminf(mn, s_red[k]);
-            mx = fmaxf(mx, s_red[8 + k]);
-            se += s_red[16 + k];
+        for (int im = 0; im < IMG; ++im) {
+            if (im < nimg) {
+                const float *rd = s_red + im * 24;
+                float lo = rd[0], hi = rd[8], sum = rd[16];
+#pragma unroll
+                for (int k = 1; k < 8; ++k) {
+                    lo = fminf(lo, rd[k]);
+                    hi = fmaxf(hi, rd[8 + k]);
+                    sum += rd[16 + k];
+                }
+                const float range = hi - lo;
+                float *d01 = a.img01 + (size_t)(img0 + im) * GR_NPIX;
+                for (int i = tid; i < GR_NPIX; i += 512) d01[i] = (s_img[im * GR_NPIX + i] - lo) / range;  // each thread rescales the pixels it wrote
+                if (a.mse && tid == 0) a.mse[img0 + im] = sum / (float)GR_NPIX;
+            }
         }
-        const float range = mx - mn;
-        float *d01 = a.img01 + (size_t)n * GR_NPIX;
-        for (int i = tid; i < GR_NPIX; i += 512) d01[i] = (s_img[i] - mn) / range;  // each thread rescales the pixels it wrote
-        if (a.mse && tid == 0) a.mse[n] = se / (float)GR_NPIX;
-        __syncthreads();  // the next image reuses s_img / s_red
     }
 }
 

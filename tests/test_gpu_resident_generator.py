@@ -66,7 +66,8 @@ def test_reference_activations(eng, synth, tag, zd):
     np.testing.assert_allclose(img, g[tag + "_img"][:, 0], atol=TOL)
     np.testing.assert_allclose(img01, g[tag + "_img01"][:, 0], atol=TOL)
     tiled, tiled01, _ = _images(eng, ev, z, False)
-    assert not np.array_equal(img, tiled)  # (the other path did run)
+    # (the other path did run; a process started with GDPSO_GEN_RESIDENT=0 packs generators without the resident form)
+    assert not np.array_equal(img, tiled) or not ENV_GEN
     np.testing.assert_allclose(img, tiled, atol=2e-5)
 
 
@@ -112,6 +113,8 @@ def test_inverter_error_of_the_launch(eng, synth, zd):
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_one_and_two_images_a_workgroup_give_the_same_bits(eng, lib, synth, dtype):
+    if not ENV_GEN:
+        pytest.skip("generators are packed without the resident form in this process (the tiled kernels' sums depend on the batch)")
     ev = _evaluator(eng, synth, 10, dtype)
     z = torch.from_numpy(np.random.RandomState(9).standard_normal((161, 10))).cuda()
     out = []

@@ -1,10 +1,16 @@
 #!/bin/bash
 # The GPU test suite under each development-switch combination (run on the GPU box from the
 # repository root); writes gpurun_out/switch_matrix.txt.  Stops at the first failing run.
+#   bash tools/switch_matrix.sh [first row] [last row]     (rows count from 1; a run takes ~105 s: eight rows to a call)
 set -e
+FIRST=${1:-1}
+LAST=${2:-1000}
 OUT=gpurun_out/switch_matrix.txt
-: > $OUT
+[ "$FIRST" -gt 1 ] || : > $OUT
+ROW=0
 run() {
+    ROW=$((ROW + 1))
+    if [ $ROW -lt $FIRST ] || [ $ROW -gt $LAST ]; then return 0; fi
     echo "== ${*:-defaults}" >> $OUT
     env "$@" timeout -k 10 300 python3 -u -m pytest tests -m gpu -x -q --timeout 200 --timeout-method thread > gpurun_out/switch_run.log 2>&1 || { tail -n 30 gpurun_out/switch_run.log >> $OUT; exit 1; }
     tail -n 1 gpurun_out/switch_run.log >> $OUT
