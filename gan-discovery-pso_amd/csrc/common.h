@@ -206,6 +206,8 @@ bool resident_stage_second(const ResidentStage *s, int n_images);
 // The reference's generator (Z -> 128 x 7 x 7 -> 64 x 14 x 14 -> 28 x 28) in one launch with its maps resident in LDS.
 struct ResidentGenerator;
 bool resident_generator_enabled();
+// Images a workgroup of the generator's launch takes for a batch planned as n_images: 0 (tiled kernels), 1 or 2.
+int resident_generator_images(int n_images, int num_cus, int dtype);
 // w1t / sc1 / sh1: the first layer as gen_first_kernel takes it (device); w3: the second layer's torch weight (host);
 // l2: that layer (its device scale / shift are shared); w5: the last layer [16][64] (device).  *out stays null (and
 // GDPSO_OK is returned) when the device cannot run the kernel.

@@ -890,7 +890,7 @@ extern "C" int gdpso_generator_forward(const gdpso_generator *g, void *stream_, 
     if ((rc = conv_splitk_prepare(stream, sk))) return rc;
     // the whole generator in one launch with its maps in LDS, at the batch sizes the resident launches serve (the
     // first layer too when the latents are short; else it stays a GEMM on the matrix cores and the launch reads its map)
-    const int resident_images = g->resident && resident_generator_enabled() ? resident_stage_images(plan_batch(n), g->num_cus) : 0;
+    const int resident_images = g->resident ? resident_generator_images(plan_batch(n), g->num_cus, g->dtype) : 0;
     if (resident_images > 0) {
         if (g->first_direct)
             return launch_resident_generator(g->resident, stream, n, resident_images, g->num_cus, z, z_is_f64, nullptr, img, img01, target, mse);

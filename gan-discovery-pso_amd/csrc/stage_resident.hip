@@ -1003,9 +1003,11 @@ int launch_resident_stage(const ResidentStage *s, hipStream_t stream, int n_imag
 }
 
 // ---- the resident generator (host side)
-static bool g_gr_enabled = [] {
+// 0: never; 1: where the launch is expected to beat the tiled kernels (resident_generator_images); 2: wherever the
+// resident launches' batch limits allow.
+static int g_gr_mode = [] {
     const char *e = getenv("GDPSO_GEN_RESIDENT");
-    return e ? e[0] != '0' : true;
+    return e ? (e[0] == '0' ? 0 : e[0] == '2' ? 2 : 1) : 1;
 }();
 
 struct ResidentGenerator {
@@ -1016,7 +1018,21 @@ struct ResidentGenerator {
     double flops, first_flops, executed2, executed1, weight_bytes;
 };
 
-bool resident_generator_enabled() { return g_gr_enabled; }
+bool resident_generator_enabled() { return g_gr_mode != 0; }
+
+// Images a workgroup of the generator's launch takes for a batch planned as n_images (0: the tiled kernels).  Within
+// the batch limits of the resident launches; with 16-bit storage always (the tiled launches are bound by their fixed
+// costs there: +2 ... 3.5 % at 64 ... 512 images); in fp32 the launch is bound by the matrix pipe of the CUs that got
+// a workgroup, so it pays only when (nearly) every CU has one: priced in units of a two-image round (a one-image round
+// 0.55) against the tiled kernels' 1.11 per 2 x num_cus images (measured: 64 images -4 %, 128 -2.5 %, 192 -0.8 %,
+// 256 +0.6 %, 384 -0.8 %, 512 +0.9 %, 768 and more ahead).
+int resident_generator_images(int n_images, int num_cus, int dtype) {
+    const int images = g_gr_mode == 0 ? 0 : resident_stage_images(n_images, num_cus);
+    if (images == 0 || g_gr_mode == 2 || dtype != DT_F32 || g_rs_force_images > 0) return images;
+    const int round = 2 * num_cus, full = n_images / round, r = n_images % round;
+    const double last = r == 0 ? 0.0 : r <= num_cus ? 0.55 : 1.0;
+    return full + last <= 1.11 * n_images / round ? images : 0;
+}
 void resident_generator_free(ResidentGenerator *g) { delete g; }
 
 // w3: the second layer's torch weight [128][64][4][4] (ConvTranspose2d layout [cin][cout][ky][kx]).
@@ -1162,8 +1178,10 @@ extern "C" int gdpso_resident_options(int stages, int max_images, int min_images
     return GDPSO_OK;
 }
 
-extern "C" int gdpso_resident_generator_option(int enabled) {
-    gdpso::g_gr_enabled = enabled != 0;
+extern "C" int gdpso_resident_generator_option(int mode) {
+    using namespace gdpso;
+    GDPSO_REQUIRE(mode >= 0 && mode <= 2, "resident_generator_option: 0 (off), 1 (where it pays) or 2 (wherever the batch limits allow)");
+    g_gr_mode = mode;
     return GDPSO_OK;
 }
 

@@ -154,10 +154,11 @@ def resident_options(stages: int = 2, max_images: int = 0, min_images: int = 0) 
     check(_lib.lib().gdpso_resident_options(int(stages), int(max_images), int(min_images)))
 
 
-def resident_generator(enabled: bool = True) -> None:
-    """The generator of the reference's shape as one launch with its maps in LDS (gdpso_resident_generator_option),
-    at the batch sizes of the resident launches; False: the tiled kernels.  From the next forward call."""
-    check(_lib.lib().gdpso_resident_generator_option(int(bool(enabled))))
+def resident_generator(mode=1) -> None:
+    """The generator of the reference's shape as one launch with its maps in LDS (gdpso_resident_generator_option).
+    0 / False: the tiled kernels; 1 / True: where the one launch is expected to be faster (default); 2: wherever the
+    batch limits of the resident launches allow.  From the next forward call."""
+    check(_lib.lib().gdpso_resident_generator_option(int(mode)))
 
 
 class _Handle:

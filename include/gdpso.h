@@ -422,15 +422,17 @@ int gdpso_plan_options(int plan_images, int splitk);
  * GDPSO_STAGE1_RESIDENT_MAX, GDPSO_STAGE1_RESIDENT_MIN give the initial values. */
 int gdpso_resident_options(int stages, int max_images, int min_images);
 
-/* No counterpart in the reference (its generator is three torch modules, src/utils/util_dcgan.py:128-149): at
- * the batch sizes gdpso_resident_options gives the resident launches, a generator of the reference's shape
- * (28x28 images, 64 features, first kernel 7) runs as ONE launch: a workgroup takes one or two latents, keeps
- * the 7x7x128 and 14x14x64 maps in LDS, streams the second layer's weights per output phase and writes the image
- * (and its [0,1] copy, and the inverter's mean squared error).  Latents of more than 16 dimensions keep their first
- * layer as a GEMM launch in front.  enabled = 0: the tiled kernels at every batch size.  Takes effect from the next
- * forward call.  First and last layer add in the tiled kernels' order; the second layer's sums are ordered
- * differently (fp32 rounding apart).  Environment: GDPSO_GEN_RESIDENT (0: off) gives the initial value. */
-int gdpso_resident_generator_option(int enabled);
+/* No counterpart in the reference (its generator is three torch modules, src/utils/util_dcgan.py:128-149): a
+ * generator of the reference's shape (28x28 images, 64 features, first kernel 7) can run as ONE launch: a workgroup
+ * takes one or two latents, keeps the 7x7x128 and 14x14x64 maps in LDS, streams the second layer's weights per output
+ * phase and writes the image (and its [0,1] copy, and the inverter's mean squared error).  Latents of more than 16
+ * dimensions keep their first layer as a GEMM launch in front.  mode = 0: the tiled kernels at every batch size;
+ * 1 (default): the one launch where it is expected to be faster, within the batch limits of
+ * gdpso_resident_options (16-bit storage: everywhere; fp32: where nearly every CU gets a workgroup, e.g. 256 or from
+ * 512 images on with 256 CUs); 2: wherever those limits allow (tests).  Takes effect from the next forward call.
+ * First and last layer add in the tiled kernels' order; the second layer's sums are ordered differently (fp32
+ * rounding apart).  Environment: GDPSO_GEN_RESIDENT (0, 1, 2) gives the initial value. */
+int gdpso_resident_generator_option(int mode);
 
 /* No counterpart in the reference: a test aid.  Launch plans made from now on give every workgroup of the
  * resident launch this many images (1 or 2) whatever the batch size (within the limits of

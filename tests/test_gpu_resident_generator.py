@@ -14,7 +14,7 @@ from conftest import load_golden
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 # what the process started with (tools/switch_matrix.sh runs the suite under the environment switches): restored after every case
-ENV_GEN = os.environ.get("GDPSO_GEN_RESIDENT", "1") != "0"
+ENV_GEN = int(os.environ.get("GDPSO_GEN_RESIDENT", "1")[:1])
 ENV_STAGES = 0 if os.environ.get("GDPSO_STAGE1_RESIDENT", "1") == "0" else 1 if os.environ.get("GDPSO_STAGE2_RESIDENT", "1") == "0" else 2
 ENV_MAX = int(os.environ.get("GDPSO_STAGE1_RESIDENT_MAX", str(1 << 30)))
 ENV_MIN = int(os.environ.get("GDPSO_STAGE1_RESIDENT_MIN", "64"))
@@ -40,7 +40,8 @@ def _evaluator(eng, synth, zd, dtype="f32"):
 def _images(eng, ev, z, resident, target=None, min_images=1):
     """(img, img01, mse | None) as numpy, the resident launch on or off at every batch size from min_images on."""
     eng.resident_options(2, 1 << 30, min_images)
-    eng.resident_generator(resident)
+    # (True: at every batch size within the limits, not only where the launch pays; an int: that mode of the option)
+    eng.resident_generator((2 if resident else 0) if isinstance(resident, bool) else resident)
     try:
         out = []
         for _ in range(2):
@@ -149,6 +150,22 @@ def test_16bit_storage(eng, synth, oracle, dtype, bar, zd):
         want = oracle.generator_forward(gsd, torch.from_numpy(zh[sel]).float().reshape(len(sel), zd, 1, 1))[:, 0].numpy()
     np.testing.assert_allclose(img[sel], want, atol=bar)
     assert np.abs(img[sel] - want).mean() <= 1.5 * np.abs(tiled[sel] - want).mean() + 1e-4
+
+
+def test_planner_keeps_fp32_batches_that_leave_cus_idle_on_the_tiled_kernels(eng, synth):
+    """Mode 1 (the default): in fp32 the one launch is bound by the matrix pipe of the CUs that got a workgroup, so a
+    batch of half an image per CU stays with the tiled kernels and one of two images per CU takes the launch; with
+    16-bit storage the launch is taken either way."""
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    ev = _evaluator(eng, synth, 10)
+    rs = np.random.RandomState(23)
+    small, full = (torch.from_numpy(rs.standard_normal((n, 10))).cuda() for n in (cus // 2, 2 * cus))
+    np.testing.assert_array_equal(_images(eng, ev, small, 1, min_images=64)[0], _images(eng, ev, small, 0, min_images=64)[0])
+    np.testing.assert_array_equal(_images(eng, ev, full, 1, min_images=64)[0], _images(eng, ev, full, 2, min_images=64)[0])
+    assert not np.array_equal(_images(eng, ev, full, 1, min_images=64)[0], _images(eng, ev, full, 0, min_images=64)[0])
+    ev16 = _evaluator(eng, synth, 10, "bf16")
+    # (with 16-bit storage the two paths' images can agree bit for bit: a layer's rounding hides the order of its sums)
+    np.testing.assert_array_equal(_images(eng, ev16, small, 1, min_images=64)[0], _images(eng, ev16, small, 2, min_images=64)[0])
 
 
 def test_limits_and_other_shapes_keep_the_tiled_kernels(eng, synth):
