@@ -107,6 +107,7 @@ _PROTOTYPES = {
     "gdpso_resident_options": (c_int, [c_int, c_int, c_int]),
     "gdpso_resident_force_images": (c_int, [c_int]),
     "gdpso_resident_generator_option": (c_int, [c_int]),
+    "gdpso_resident_describe": (c_int, [c_int, c_int, c_int] + [C.POINTER(c_int)] * 4),
     "gdpso_chain_tile_describe": (c_int, [c_int] * 10),
     "gdpso_conv_probe": (c_int, [c_int] * 11 + [C.POINTER(c_double), C.POINTER(c_int), C.POINTER(c_int)]),
     "gdpso_conv_probe_typed": (c_int, [c_int] * 11 + [C.POINTER(c_double), C.POINTER(c_int), C.POINTER(c_int), c_int]),

@@ -1185,6 +1185,19 @@ extern "C" int gdpso_resident_generator_option(int mode) {
     return GDPSO_OK;
 }
 
+extern "C" int gdpso_resident_describe(int n_images, int num_cus, int dtype, int *stage_images, int *tail_images, int *second_stage,
+                                       int *generator_images) {
+    using namespace gdpso;
+    GDPSO_REQUIRE(n_images > 0 && num_cus > 0, "resident_describe: n_images and num_cus must be positive");
+    GDPSO_REQUIRE(dtype == DT_F32 || dtype == DT_BF16 || dtype == DT_F16, "resident_describe: unknown element type");
+    const int images = g_rs_enabled ? resident_stage_images(n_images, num_cus) : 0;
+    if (stage_images) *stage_images = images;
+    if (tail_images) *tail_images = resident_tail_images(n_images, images, num_cus);
+    if (second_stage) *second_stage = images > 0 && g_rs_stage2 && n_images >= g_rs2_min_images ? 1 : 0;
+    if (generator_images) *generator_images = resident_generator_images(n_images, num_cus, dtype);
+    return GDPSO_OK;
+}
+
 extern "C" int gdpso_resident_force_images(int images_per_workgroup) {
     using namespace gdpso;
     GDPSO_REQUIRE(images_per_workgroup >= 0 && images_per_workgroup <= 2, "resident_force_images: 0 (planner's choice), 1 or 2");

@@ -434,6 +434,16 @@ int gdpso_resident_options(int stages, int max_images, int min_images);
  * rounding apart).  Environment: GDPSO_GEN_RESIDENT (0, 1, 2) gives the initial value. */
 int gdpso_resident_generator_option(int mode);
 
+/* No counterpart in the reference: what the planner of the resident launches decides for a batch planned as
+ * n_images on a device of num_cus CUs, under the current options.  Host only (no GPU call): lets a test check the
+ * choice without a device.  *stage_images: images a workgroup of the assessor's launch takes (0: the tiled kernels
+ * and the chained launch); *tail_images: how many of the batch's last images form a last round that runs as a second
+ * launch with one image a workgroup (0: none); *second_stage: 1 when the launch goes on through the second ResNet
+ * stage of an assessor that has one within the launch's limits; *generator_images: as stage_images, for the
+ * generator's launch with networks of element type dtype.  Any of the four may be NULL. */
+int gdpso_resident_describe(int n_images, int num_cus, int dtype, int *stage_images, int *tail_images, int *second_stage,
+                            int *generator_images);
+
 /* No counterpart in the reference: a test aid.  Launch plans made from now on give every workgroup of the
  * resident launch this many images (1 or 2) whatever the batch size (within the limits of
  * gdpso_resident_options); 0: the planner chooses again.  The two forms give an image the same bits. */

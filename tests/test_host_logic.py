@@ -207,6 +207,40 @@ def test_chain_tile_choice(pkg):
     assert f(512, 2, 1024, 256, 1, 1, 0, 256, 3, F32) < 0
 
 
+def test_resident_launch_planner(pkg):
+    """What the resident launches do with a batch (host logic only): below 64 images the tiled kernels; one image a
+    workgroup up to one image per CU, two beyond; batches of several rounds of workgroups with a short last round
+    as a one-image launch of its own; the second stage from 160 images on; the generator's launch in fp32 only where
+    nearly every CU gets a workgroup, with 16-bit storage wherever the assessor's runs."""
+    import ctypes as C
+    L = importlib.import_module("gan-discovery-pso_amd._lib")
+    if any(os.environ.get(k) for k in ("GDPSO_STAGE1_RESIDENT", "GDPSO_STAGE2_RESIDENT", "GDPSO_STAGE1_RESIDENT_MIN", "GDPSO_STAGE1_RESIDENT_MAX",
+                                       "GDPSO_STAGE2_RESIDENT_MIN", "GDPSO_GEN_RESIDENT", "GDPSO_RESIDENT_TAIL")):
+        pytest.skip("the planner's defaults are overridden in this process")
+    F32, BF16 = 0, 1
+
+    def plan(n, dtype=F32, cus=256):
+        out = [C.c_int(-1) for _ in range(4)]
+        L.check(L.lib().gdpso_resident_describe(n, cus, dtype, *[C.byref(o) for o in out]))
+        return tuple(o.value for o in out)  # stage images, tail images, second stage, generator images
+
+    assert plan(32) == (0, 0, 0, 0)
+    assert plan(64) == (1, 0, 0, 0) and plan(64, BF16) == (1, 0, 0, 1)
+    assert plan(159)[2] == 0 and plan(160)[2] == 1
+    assert plan(256) == (1, 0, 1, 1)            # every CU a workgroup: the generator's launch pays in fp32 too
+    assert plan(257) == (2, 0, 1, 0) and plan(384) == (2, 0, 1, 0) and plan(384, BF16) == (2, 0, 1, 2)
+    assert plan(512) == (2, 0, 1, 2)
+    assert plan(768) == (2, 256, 1, 2)          # one and a half rounds: 512 images two a workgroup, 256 one a workgroup
+    assert plan(769) == (2, 0, 1, 0)            # a last round of more than one image per CU stays with two (fp32 generator: tiled)
+    assert plan(1024) == (2, 0, 1, 2) and plan(1100) == (2, 76, 1, 0) and plan(1100, BF16) == (2, 76, 1, 2)
+    assert plan(16384) == (2, 0, 1, 2)
+    assert plan(100, cus=64) == (2, 0, 0, 0) and plan(200, cus=64) == (2, 0, 1, 0)  # 64 CUs: 200 = a round of 128 and 72 more
+    assert plan(256, cus=64) == (2, 0, 1, 2)
+    assert plan(200, cus=64)[1] == 0 and plan(190, cus=64)[1] == 62
+    assert L.lib().gdpso_resident_describe(0, 256, F32, None, None, None, None) != 0
+    assert L.lib().gdpso_resident_describe(64, 256, 7, None, None, None, None) != 0
+
+
 def test_conv_window_larger_than_the_tap_table_is_refused(pkg):
     """A k x k window with more taps than a phase's table holds (64), or offsets beyond int8, is an
     argument error at the C ABI, not a write past the table."""
