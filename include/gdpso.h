@@ -391,8 +391,10 @@ unsigned gdpso_fast_div_check(unsigned n, unsigned d);
  * path for an uneven deal of workgroups to XCDs (a test aid; results do not change); teams (0: keep,
  * 1, 2): teams of workgroups per XCD in plans made from now on (two teams each own a sixteenth of the
  * images and walk the layers independently; measured slower than one on MI355X, kept as an A/B switch).
- * Chains run on a device only while the library has seen a single stream there;
- * every call also forgets the streams seen so far. */
+ * Chains run on a device only while the library has seen a single stream there (a persistent grid holds
+ * every CU while its workgroups wait for each other, so work on a second stream could keep it from becoming
+ * resident; when a second stream appears the library drains the first once and launches per layer from then
+ * on); every call also forgets the streams seen so far. */
 int gdpso_chain_debug(int enabled, unsigned drop_xcc_mask, int teams);
 
 /* No counterpart in the reference (one process, one batch size): options of the launch plans made from
