@@ -186,7 +186,7 @@ struct DeviceArena;
 struct ConvLayer;
 bool resident_stage_enabled();
 // Images a workgroup of the resident launch takes for a batch planned as n_images (1 or 2), or 0: the tiled kernels.
-int resident_stage_images(int n_images, int num_cus);
+int resident_stage_images(int n_images, int num_cus, int dtype);
 // *out stays null (and GDPSO_OK is returned) when the device cannot run the kernel.
 int resident_stage_new(DeviceArena &arena, int dtype, int nblocks, const float *const *w, const float *w_ds, const ConvLayer *const *c1,
                        const ConvLayer *const *c2, const ConvLayer *const *c3, const ConvLayer *ds, const float *stem_w,

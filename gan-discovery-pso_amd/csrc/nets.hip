@@ -1041,7 +1041,7 @@ std::shared_ptr<const AssLayout> ass_layout(const gdpso_assessor *a, int n) {
     // launches not to matter, and two of its three layers per block already share one).  The chain reads
     // the first stage's output where it lies, keeps its intermediates in per-share slices of y-or-x / z /
     // t1 / t2 / sc and writes the last block's output to a buffer of its own.
-    L.resident_images = a->resident != nullptr ? resident_stage_images(plan_batch(n), a->num_cus) : 0;
+    L.resident_images = a->resident != nullptr ? resident_stage_images(plan_batch(n), a->num_cus, a->dtype) : 0;
     L.resident = L.resident_images > 0;
     // (a chain picks up behind the resident launch: behind the first stage, or behind the second)
     L.resident_second = L.resident && resident_stage_second(a->resident, plan_batch(n));

@@ -783,12 +783,15 @@ static int g_rs_max_images = [] {
     const char *e = getenv("GDPSO_STAGE1_RESIDENT_MAX");
     return e ? atoi(e) : RS_NO_LIMIT;
 }();
-// Smallest batch that takes it: below, a handful of workgroups walk some sixty layers on a few CUs while the tiled
-// kernels spread every layer over the device.
+// Smallest batch that takes it, 0: by the element type.  fp32, 64: below, a handful of workgroups walk some sixty
+// layers on a few CUs, bound by their matrix pipes, while the tiled kernels spread every layer over the device.
+// 16-bit storage, 1: there the tiled launches are bound by their fixed costs, and one launch for some fifteen wins at
+// every size (32 images: 114 k -> 148 k particle-evals/s).
 static int g_rs_min_images = [] {
     const char *e = getenv("GDPSO_STAGE1_RESIDENT_MIN");
-    return e ? atoi(e) : 64;
+    return e ? atoi(e) : 0;
 }();
+static int rs_min_images(int dtype) { return g_rs_min_images > 0 ? g_rs_min_images : dtype == DT_F32 ? 64 : 1; }
 
 struct ResidentStage {
     int dtype;
@@ -808,10 +811,12 @@ static bool g_rs_stage2 = [] {
     return e ? e[0] != '0' : true;
 }();
 
+// Smallest batch whose launch goes on through the second stage, 0: by the element type (fp32: 160, 16-bit: 1).
 static int g_rs2_min_images = [] {
     const char *e = getenv("GDPSO_STAGE2_RESIDENT_MIN");
-    return e ? atoi(e) : 160;
+    return e ? atoi(e) : 0;
 }();
+static int rs2_min_images(int dtype) { return g_rs2_min_images > 0 ? g_rs2_min_images : dtype == DT_F32 ? 160 : 1; }
 static int g_rs_force_images = 0;  // test aid (gdpso_resident_force_images)
 
 bool resident_stage_enabled() { return g_rs_enabled; }
@@ -933,8 +938,8 @@ static int resident_tail_images(int n_images, int images_per_wg, int num_cus) {
 // on MI355X (256 CUs, fp32) against the tiled kernels at 600 ... 16384 images: ahead at every size, by 0.5 % (600
 // images: a last round of 88 workgroups) to 9 % (768).  Without the one-image last round (GDPSO_RESIDENT_TAIL=0)
 // only batches whose rounds come out at least 85 % full take the launch (768 images: 6 % behind the tiled kernels).
-int resident_stage_images(int n_images, int num_cus) {
-    if (n_images < g_rs_min_images || n_images > g_rs_max_images) return 0;
+int resident_stage_images(int n_images, int num_cus, int dtype) {
+    if (n_images < rs_min_images(dtype) || n_images > g_rs_max_images) return 0;
     if (g_rs_force_images > 0) return g_rs_force_images;
     if (n_images <= num_cus) return 1;
     if (n_images <= 2 * num_cus || g_rs_tail_single) return 2;
@@ -942,10 +947,12 @@ int resident_stage_images(int n_images, int num_cus) {
     return (long)n_images * 100 >= capacity * 85 ? 2 : 0;
 }
 
-// Whether the launch should go on through the second stage for a batch planned as n_images: with few workgroups
-// its long layers on a handful of CUs lose to the chained launch, which spreads them over the device (measured:
-// even at 128 images, +6 % at 192, +5 % at 256).
-bool resident_stage_second(const ResidentStage *s, int n_images) { return s != nullptr && s->stage2 && n_images >= g_rs2_min_images; }
+// Whether the launch should go on through the second stage for a batch planned as n_images: in fp32, with few
+// workgroups, its long layers on a handful of CUs lose to the chained launch, which spreads them over the device
+// (measured: even at 128 images, +6 % at 192, +5 % at 256); with 16-bit storage it pays at every size (+8 % at 64 and 128).
+bool resident_stage_second(const ResidentStage *s, int n_images) {
+    return s != nullptr && s->stage2 && n_images >= rs2_min_images(s->dtype);
+}
 
 static int launch_resident_stage_part(const ResidentStage *s, hipStream_t stream, int n_images, int images_per_wg, bool second,
                                       const float *img01, void *out, void *zero, int zero_quads) {
@@ -1027,7 +1034,7 @@ bool resident_generator_enabled() { return g_gr_mode != 0; }
 // 0.55) against the tiled kernels' 1.11 per 2 x num_cus images (measured: 64 images -4 %, 128 -2.5 %, 192 -0.8 %,
 // 256 +0.6 %, 384 -0.8 %, 512 +0.9 %, 768 and more ahead).
 int resident_generator_images(int n_images, int num_cus, int dtype) {
-    const int images = g_gr_mode == 0 ? 0 : resident_stage_images(n_images, num_cus);
+    const int images = g_gr_mode == 0 ? 0 : resident_stage_images(n_images, num_cus, dtype);
     if (images == 0 || g_gr_mode == 2 || dtype != DT_F32 || g_rs_force_images > 0) return images;
     const int round = 2 * num_cus, full = n_images / round, r = n_images % round;
     const double last = r == 0 ? 0.0 : r <= num_cus ? 0.55 : 1.0;
@@ -1170,11 +1177,11 @@ int launch_resident_generator(const ResidentGenerator *g, hipStream_t stream, in
 extern "C" int gdpso_resident_options(int stages, int max_images, int min_images) {
     using namespace gdpso;
     GDPSO_REQUIRE(stages >= 0 && stages <= 2, "resident_options: stages must be 0, 1 or 2");
-    GDPSO_REQUIRE(max_images >= 0 && min_images >= 0, "resident_options: max_images / min_images must be 0 (keep) or a batch size");
-    if (min_images > 0) g_rs_min_images = min_images;
+    GDPSO_REQUIRE(max_images >= -1 && min_images >= -1, "resident_options: max_images / min_images must be 0 (keep), -1 (default) or a batch size");
+    if (min_images != 0) g_rs_min_images = min_images > 0 ? min_images : 0;  // (0 inside: by the element type)
     g_rs_enabled = stages != 0;
     g_rs_stage2 = stages == 2;
-    if (max_images > 0) g_rs_max_images = max_images;
+    if (max_images != 0) g_rs_max_images = max_images > 0 ? max_images : RS_NO_LIMIT;
     return GDPSO_OK;
 }
 
@@ -1190,10 +1197,10 @@ extern "C" int gdpso_resident_describe(int n_images, int num_cus, int dtype, int
     using namespace gdpso;
     GDPSO_REQUIRE(n_images > 0 && num_cus > 0, "resident_describe: n_images and num_cus must be positive");
     GDPSO_REQUIRE(dtype == DT_F32 || dtype == DT_BF16 || dtype == DT_F16, "resident_describe: unknown element type");
-    const int images = g_rs_enabled ? resident_stage_images(n_images, num_cus) : 0;
+    const int images = g_rs_enabled ? resident_stage_images(n_images, num_cus, dtype) : 0;
     if (stage_images) *stage_images = images;
     if (tail_images) *tail_images = resident_tail_images(n_images, images, num_cus);
-    if (second_stage) *second_stage = images > 0 && g_rs_stage2 && n_images >= g_rs2_min_images ? 1 : 0;
+    if (second_stage) *second_stage = images > 0 && g_rs_stage2 && n_images >= rs2_min_images(dtype) ? 1 : 0;
     if (generator_images) *generator_images = resident_generator_images(n_images, num_cus, dtype);
     return GDPSO_OK;
 }

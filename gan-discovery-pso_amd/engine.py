@@ -149,8 +149,8 @@ def resident_options(stages: int = 2, max_images: int = 0, min_images: int = 0) 
     """Switches of the resident stages (gdpso_resident_options; pack the assessor AFTER the call).
     ``stages`` 0: stem and every ResNet stage through the tiled convolution kernels; 1: stem and first stage
     in one launch with their maps in LDS; 2 (default): the second stage too.  ``max_images`` / ``min_images``
-    > 0: largest / smallest planned batch that takes the resident kernel (0: keep the current limit; defaults
-    none and 64).  The paths agree to fp32 rounding, not bit for bit."""
+    > 0: largest / smallest planned batch that takes the resident kernel (0: keep the current limit; -1: the
+    default, which is no upper limit and 64 images below for fp32 networks, 1 with 16-bit storage).  The paths agree to fp32 rounding, not bit for bit."""
     check(_lib.lib().gdpso_resident_options(int(stages), int(max_images), int(min_images)))
 
 

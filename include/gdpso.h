@@ -415,13 +415,15 @@ int gdpso_plan_options(int plan_images, int splitk);
  * created and launch plans made from now on.  stages = 0: stem and every stage run through the tiled kernels
  * (A/B runs and tests); 1: the stem and the first stage are resident; 2 (default): the second stage as well.
  * max_images / min_images > 0: the largest / smallest (planned, see gdpso_plan_options) batch that takes the
- * resident kernel; 0 keeps the current limit (defaults: no upper limit, 64 below: smaller batches leave most CUs
- * without a workgroup; a workgroup takes one image up to one image per CU, two beyond, and batches of more than
- * two images per CU run in rounds of two images a workgroup with a last round of at most one image per CU as a
- * launch of its own with one image a workgroup).  The paths
- * add a row's products in different orders and agree to fp32 rounding (to the element type's rounding for 16-bit
- * storage).  Environment: GDPSO_STAGE1_RESIDENT (0: none), GDPSO_STAGE2_RESIDENT (0: first stage only),
- * GDPSO_STAGE1_RESIDENT_MAX, GDPSO_STAGE1_RESIDENT_MIN give the initial values. */
+ * resident kernel; 0 keeps the current limit, -1 goes back to the default: no upper limit; below, 64 images for fp32
+ * networks (smaller batches leave most CUs without a workgroup, and a workgroup is bound by its CU's matrix pipe) and 1
+ * with 16-bit storage (there the tiled launches are bound by their fixed costs and one launch for fifteen wins at
+ * every size).  A workgroup takes one image up to one image per CU, two beyond, and batches of more than two images
+ * per CU run in rounds of two images a workgroup with a last round of at most one image per CU as a launch of its own
+ * with one image a workgroup.  The second stage rides along from 160 images on in fp32, always with 16-bit storage.
+ * The paths add a row's products in different orders and agree to fp32 rounding (to the element type's rounding for
+ * 16-bit storage).  Environment: GDPSO_STAGE1_RESIDENT (0: none), GDPSO_STAGE2_RESIDENT (0: first stage only),
+ * GDPSO_STAGE1_RESIDENT_MAX, GDPSO_STAGE1_RESIDENT_MIN, GDPSO_STAGE2_RESIDENT_MIN give the initial values. */
 int gdpso_resident_options(int stages, int max_images, int min_images);
 
 /* No counterpart in the reference (its generator is three torch modules, src/utils/util_dcgan.py:128-149): a

@@ -16,8 +16,8 @@ TOL = 1e-4
 # what the process started with (tools/switch_matrix.sh runs the suite under the environment switches): restored after every case
 ENV_GEN = int(os.environ.get("GDPSO_GEN_RESIDENT", "1")[:1])
 ENV_STAGES = 0 if os.environ.get("GDPSO_STAGE1_RESIDENT", "1") == "0" else 1 if os.environ.get("GDPSO_STAGE2_RESIDENT", "1") == "0" else 2
-ENV_MAX = int(os.environ.get("GDPSO_STAGE1_RESIDENT_MAX", str(1 << 30)))
-ENV_MIN = int(os.environ.get("GDPSO_STAGE1_RESIDENT_MIN", "64"))
+ENV_MAX = int(os.environ.get("GDPSO_STAGE1_RESIDENT_MAX", "-1"))  # (-1: the library's default)
+ENV_MIN = int(os.environ.get("GDPSO_STAGE1_RESIDENT_MIN", "-1"))
 
 
 @pytest.fixture(scope="module")

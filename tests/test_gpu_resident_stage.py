@@ -13,8 +13,8 @@ import os
 pytestmark = pytest.mark.gpu
 # what the process started with (tools/switch_matrix.sh runs the suite under the environment switches): restored after every case
 ENV_STAGES = 0 if os.environ.get("GDPSO_STAGE1_RESIDENT", "1") == "0" else 1 if os.environ.get("GDPSO_STAGE2_RESIDENT", "1") == "0" else 2
-ENV_MAX = int(os.environ.get("GDPSO_STAGE1_RESIDENT_MAX", str(1 << 30)))
-ENV_MIN = int(os.environ.get("GDPSO_STAGE1_RESIDENT_MIN", "64"))
+ENV_MAX = int(os.environ.get("GDPSO_STAGE1_RESIDENT_MAX", "-1"))  # (-1: the library's default)
+ENV_MIN = int(os.environ.get("GDPSO_STAGE1_RESIDENT_MIN", "-1"))
 # (the second stage's own lower limit is an environment switch only)
 S2_MIN = int(os.environ.get("GDPSO_STAGE2_RESIDENT_MIN", "160"))
 

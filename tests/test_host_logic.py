@@ -225,7 +225,8 @@ def test_resident_launch_planner(pkg):
         return tuple(o.value for o in out)  # stage images, tail images, second stage, generator images
 
     assert plan(32) == (0, 0, 0, 0)
-    assert plan(64) == (1, 0, 0, 0) and plan(64, BF16) == (1, 0, 0, 1)
+    assert plan(64) == (1, 0, 0, 0) and plan(64, BF16) == (1, 0, 1, 1)
+    assert plan(1, BF16) == (1, 0, 1, 1) and plan(32, BF16) == (1, 0, 1, 1)  # 16-bit storage: one launch at every size
     assert plan(159)[2] == 0 and plan(160)[2] == 1
     assert plan(256) == (1, 0, 1, 1)            # every CU a workgroup: the generator's launch pays in fp32 too
     assert plan(257) == (2, 0, 1, 0) and plan(384) == (2, 0, 1, 0) and plan(384, BF16) == (2, 0, 1, 2)
