@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede the CDLL below)
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libgdpso.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MODE_IN_TRAINING, MODE_OUT_TRAINING = 0, 1
 DTYPES = {"f32": 0, "bf16": 1, "f16": 2}  # GDPSO_DTYPE_*
 CTRL_DOUBLES = 8

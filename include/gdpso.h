@@ -28,8 +28,10 @@ extern "C" {
 
 /* 2: gdpso_swarm gained cand_stride and the candidate records two distance-sum slots (GDPSO_CAND_DOUBLES);
  *    gdpso_swarm_scratch_bytes(n) grew about eightfold (one partial record per 32 particles instead of
- *    per 256): size the scratch buffer with the function, never with a constant from an older build */
-#define GDPSO_ABI_VERSION 2
+ *    per 256): size the scratch buffer with the function, never with a constant from an older build
+ * 3: gdpso_swarm_scratch_bytes(n) holds two sets of the distance diagnostic's tile sums (the fused loops alternate
+ *    between them); gdpso_resident_options takes -1 for "the default" */
+#define GDPSO_ABI_VERSION 3
 
 #define GDPSO_OK 0
 #define GDPSO_ERR_ARG 1       /* bad argument / unsupported shape */

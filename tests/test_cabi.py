@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported(lib):
     handle = lib.lib()
     for name in header_functions():
         assert getattr(handle, name) is not None
-    assert handle.gdpso_abi_version() == lib.ABI_VERSION == 2
+    assert handle.gdpso_abi_version() == lib.ABI_VERSION == 3
 
 
 def test_struct_layouts_match_header(lib):
