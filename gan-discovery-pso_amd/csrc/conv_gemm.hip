@@ -1436,10 +1436,19 @@ size_t conv_splitk_bytes(const ConvLayer &L, int n_images) {
     return SPLITK_COUNTER_BYTES + (size_t)L.splits * n_images * L.hout * L.wout * L.cout * sizeof(float);
 }
 
-// Zeroes the arrival counters; once per forward pass, ahead of the first convolution.
+// Zeroes the arrival counters; once per forward pass, ahead of the first convolution.  A kernel, not
+// hipMemsetAsync: a memset node of a captured graph did not clear them on replay (the captured loop then left layers
+// unreduced), a kernel node does.
+__global__ __launch_bounds__(256) void clear_quads_kernel(f32x4 *__restrict__ p, int quads) {
+    const int i = (int)blockIdx.x * 256 + threadIdx.x;
+    if (i < quads) p[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
 int conv_splitk_prepare(hipStream_t stream, float *splitk_ws) {
     if (g_fused_max_splits <= 0) return GDPSO_OK;  // the counters are only read by the in-kernel reduction
-    GDPSO_HIP(hipMemsetAsync(splitk_ws, 0, SPLITK_COUNTER_BYTES, stream));
+    constexpr int quads = (int)(SPLITK_COUNTER_BYTES / 16);
+    hipLaunchKernelGGL(clear_quads_kernel, dim3(ceil_div(quads, 256)), dim3(256), 0, stream, (f32x4 *)splitk_ws, quads);
+    GDPSO_HIP(hipGetLastError());
     return GDPSO_OK;
 }
 
@@ -1863,7 +1872,12 @@ int launch_chain(const ConvChain *c, hipStream_t stream, void *workspace, bool c
     char *ws = (char *)workspace;
     ChainCtl *ctl = (ChainCtl *)(ws + c->ctl_off);
     static_assert(sizeof(ChainCtl) % 16 == 0, "the control block is cleared in 16-byte words");
-    if (!ctl_cleared) GDPSO_HIP(hipMemsetAsync(ctl, 0, sizeof(ChainCtl), stream));
+    if (!ctl_cleared) {  // (by a kernel, like the split-K counters: memset nodes of a captured graph are not relied on)
+        static_assert(sizeof(ChainCtl) % 16 == 0, "the control block is cleared in 16-byte words");
+        constexpr int quads = (int)(sizeof(ChainCtl) / 16);
+        hipLaunchKernelGGL(clear_quads_kernel, dim3(ceil_div(quads, 256)), dim3(256), 0, stream, (f32x4 *)ctl, quads);
+        GDPSO_HIP(hipGetLastError());
+    }
     const bool timed = g_timing.on && g_timing.used + 2 <= g_timing.events.size();
     const dim3 grid((unsigned)c->grid);
     if (timed) {
