@@ -156,6 +156,8 @@ def test_planner_keeps_fp32_batches_that_leave_cus_idle_on_the_tiled_kernels(eng
     """Mode 1 (the default): in fp32 the one launch is bound by the matrix pipe of the CUs that got a workgroup, so a
     batch of half an image per CU stays with the tiled kernels and one of two images per CU takes the launch; with
     16-bit storage the launch is taken either way."""
+    if not ENV_GEN:
+        pytest.skip("generators are packed without the resident form in this process")
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     ev = _evaluator(eng, synth, 10)
     rs = np.random.RandomState(23)
