@@ -10,13 +10,17 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n,d,iters", [(64, 10, 6), (512, 10, 4)])
-def test_captured_loop_replays_to_the_same_state(synth, n, d, iters):
+@pytest.mark.parametrize("n,d,iters,dtype", [(64, 10, 6, "f32"), (512, 10, 4, "f32"), (40, 10, 4, "f32"), (512, 100, 3, "bf16"),
+                                              (768, 10, 3, "f32")])
+def test_captured_loop_replays_to_the_same_state(synth, n, d, iters, dtype):
+    """64, 40: the tiled generator (and, at 40, the tiled stem and first stages); 512: the resident launches; 768: a
+    short last round of workgroups in launches of their own; bf16 with 100-dimensional latents: the first generator
+    layer as a GEMM launch, the PSO update in its multi-workgroup kernels."""
     eng = importlib.import_module("gan-discovery-pso_amd.engine")
     lib = importlib.import_module("gan-discovery-pso_amd._lib")
     dev = torch.device("cuda:0")
-    gen = eng.PackedGenerator(synth.generator_state(d, 1, 64, seed=11), dev)
-    ass = eng.PackedAssessor(synth.resnet_state("ResNet50", 1, 8, seed=12), dev, img_side=28)
+    gen = eng.PackedGenerator(synth.generator_state(d, 1, 64, seed=11), dev, dtype=dtype)
+    ass = eng.PackedAssessor(synth.resnet_state("ResNet50", 1, 8, seed=12), dev, img_side=28, dtype=dtype)
     ev = eng.Evaluator(gen, ass)
     spec = eng.FitnessSpec(class_index=2)
     sw = eng.HipSwarm(ev, n, d, iters, history=True, diagnostics=True, record_fitness=True)
