@@ -104,6 +104,8 @@ def _assert_same_run(ranks, whole, p, exact_fitness=True, upto=None):
     (8, 512, 10, 28, "f32", 5, True),     # 4096 particles over 8 ranks, fp32, 28x28
     (8, 256, 10, 64, "f16", 3, True),     # 2048 particles over 8 ranks, fp16, 64x64
     (4, 96, 100, 28, "bf16", 4, False),   # positions in a gather of their own; Z = 100, bf16
+    (3, 768, 10, 28, "f32", 3, True),     # one and a half rounds of the resident launches' workgroups per rank (a short last
+                                          # round with one image a workgroup), four and a half on the single rank
 ])
 def test_sharded_run_equals_unsharded_run(mods, synth, world, p, z_dim, side, dtype, iters, table):
     """8 logical ranks, every one evaluating its own block through the real generator and assessor, against the
