@@ -97,12 +97,13 @@ def test_matches_tiled_kernels_and_oracle(eng, synth, oracle, zd, n):
     np.testing.assert_allclose(img01[sel], want01[:, 0].numpy(), atol=TOL)
 
 
+@pytest.mark.parametrize("n", [300, 700])
 @pytest.mark.parametrize("zd", [10, 100])
-def test_inverter_error_of_the_launch(eng, synth, zd):
+def test_inverter_error_of_the_launch(eng, synth, zd, n):
     """The mean squared error of each image against its target (the inverter's fitness term, reference
-    src/utils/util_discovery.py:97) comes out of the same launch."""
+    src/utils/util_discovery.py:97) comes out of the same launch (700 images on 256 CUs: the last 188 from a second
+    launch with one image a workgroup, which reads its own targets and writes its own errors)."""
     ev = _evaluator(eng, synth, zd)
-    n = 300
     z = torch.from_numpy(np.random.RandomState(5).standard_normal((n, zd))).cuda()
     target = torch.from_numpy((2 * np.random.RandomState(6).random_sample((n, 28, 28)) - 1).astype(np.float32)).cuda()
     img, img01, mse = _images(eng, ev, z, True, target)
